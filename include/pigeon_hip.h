@@ -1,0 +1,150 @@
+/*
+ * pigeon_hip.h — C ABI of libpigeon_hip.so (gfx950 / MI355X only).
+ *
+ * Drop-in boundary for the image-generation hot path of YiyanXu/Pigeon
+ * (Pigeon/models/lavit_for_pigeon.py:674-789).  The reference has no FFI: every
+ * kernel on its path lives in third-party wheels (diffusers 0.27.2, xformers
+ * 0.0.27.dev792, torch 2.3).  Each entry point below therefore cites the
+ * reference call site (or the third-party op reached from it) that it replaces.
+ *
+ * Conventions
+ *   - plain pointers are DEVICE pointers unless the name says `host`;
+ *   - nothing here allocates, frees or synchronises: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the legacy default stream);
+ *   - return value: 0 = ok, <0 = PGN_ERR_* (argument / shape refused before any
+ *     launch), >0 = a hipError_t from the launch;
+ *   - re-entrant per stream, no global state (except the opt-in profiler ring);
+ *   - bf16 / f16 tensors are passed as raw 16-bit storage.
+ */
+#ifndef PIGEON_HIP_H
+#define PIGEON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGN_VERSION 100 /* 0.1.0 */
+
+#define PGN_OK 0
+#define PGN_ERR_INVALID (-1)     /* null pointer, non-positive size, bad enum, misalignment */
+#define PGN_ERR_UNSUPPORTED (-2) /* valid request the gfx950 kernels do not cover (e.g. head_dim) */
+
+typedef enum { PGN_F32 = 0, PGN_BF16 = 1, PGN_F16 = 2 } pgn_dtype;
+
+/* prediction types of diffusers schedulers (DDIMScheduler.step / EulerDiscreteScheduler.step) */
+typedef enum { PGN_PRED_EPSILON = 0, PGN_PRED_SAMPLE = 1, PGN_PRED_V = 2 } pgn_pred_type;
+
+/* flags for the fused step kernels */
+#define PGN_STEP_FUSED_FP32 1u /* keep every intermediate in fp32 (FMA allowed). Default (flag clear)
+                                  reproduces the reference's rounding points: CFG arithmetic and the
+                                  coefficient*eps products are rounded to the eps dtype, exactly as
+                                  torch does for `bf16_tensor op scalar` (lavit_for_pigeon.py:761,764). */
+#define PGN_STEP_CLIP_SAMPLE 2u        /* DDIM `clip_sample`: clamp pred_original_sample to +-clip_range */
+#define PGN_STEP_USE_CLIPPED_OUTPUT 4u /* DDIM `use_clipped_model_output`: re-derive eps from the clipped x0 */
+
+int pgn_version(void);
+const char* pgn_error_string(int code);
+
+/* Workspace query kept for ABI stability; every op below currently needs 0 bytes. */
+typedef enum { PGN_OP_GATHER = 0, PGN_OP_CFG_STEP = 1, PGN_OP_GROUPNORM = 2, PGN_OP_ATTENTION = 3 } pgn_op;
+size_t pgn_workspace_bytes(int op);
+
+/* ---------------------------------------------------------------------------------------------
+ * Token -> codebook-embedding gather.
+ * Replaces LaVITforPigeon.generate_image_embeds, Pigeon/models/lavit_for_pigeon.py:897-918
+ * (id - 32002, keep >= 0, truncate to 256, F.embedding on the [16384,32] fp32 codebook of
+ * Pigeon/models/modeling_visual_tokenzier.py:54-64, cast to the model dtype) and the pad/mask loop
+ * of HighresVQDecoder.forward, Pigeon/models/modeling_decoder.py:310-317.
+ *
+ * ids        int64 [offsets[B]]   concatenated raw LLM ids of B samples (ragged)
+ * offsets    int32 [B+1]          sample b owns ids[offsets[b] .. offsets[b+1])
+ * codebook   fp32  [num_codes, dim]   dim % 4 == 0
+ * token_nums int64 [B]            OUT: kept tokens per sample (<= max_tokens)
+ * out_packed out_dtype [sum(token_nums), dim]  OUT, may be NULL; caller sizes it for the worst case
+ *                                 min(len_b, max_tokens) summed over b
+ * out_padded out_dtype [B, pad_len, dim] OUT, may be NULL: right-padded with zeros
+ * out_mask   out_dtype [B, pad_len]      OUT, may be NULL: 1 for kept tokens else 0
+ * status     int32 [1]            OUT, may be NULL: set to 1 if a kept id is >= num_codes (F.embedding
+ *                                 would raise); such rows are written as zeros.  Caller zeroes it first.
+ * Bit-exact with the reference (integer index math + exact fp32->bf16 RNE cast).
+ */
+int pgn_token_gather(const int64_t* ids, const int32_t* offsets, int B, const float* codebook, int num_codes,
+                     int dim, int64_t id_offset, int max_tokens, int out_dtype, int64_t* token_nums,
+                     void* out_packed, void* out_padded, void* out_mask, int pad_len, int32_t* status,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused classifier-free-guidance combine + DDIM step (eta = 0).
+ * Replaces lavit_for_pigeon.py:760-764: `chunk(2)`, `eps_u + g*(eps_t - eps_u)` and
+ * diffusers 0.27.2 DDIMScheduler.step(...).prev_sample.
+ *
+ *   eps   = eps_u + g*(eps_t - eps_u)
+ *   epsilon:      x0 = (x - sqrt_beta_t*eps)/sqrt_alpha_t            ; e = eps
+ *   sample:       x0 = eps                                            ; e = (x - sqrt_alpha_t*x0)/sqrt_beta_t
+ *   v_prediction: x0 = sqrt_alpha_t*x - sqrt_beta_t*eps               ; e = sqrt_alpha_t*eps + sqrt_beta_t*x
+ *   (PGN_STEP_CLIP_SAMPLE clamps x0; PGN_STEP_USE_CLIPPED_OUTPUT then re-derives e from it)
+ *   prev  = sqrt_alpha_prev*x0 + dir_coef*e        with dir_coef = sqrt(1 - alpha_prev)
+ *
+ * eps_uncond/eps_text: eps_dtype [numel] (eps_uncond may be NULL: no guidance, eps = eps_text);
+ * sample/prev_sample: sample_dtype [numel] (fp32, or the same 16-bit type as eps);
+ * pred_x0 (sample_dtype, may be NULL) receives pred_original_sample.  Scalars are the fp32 values
+ * the scheduler computes on the host.  12 algorithmic bytes per element (bf16 eps, fp32 latents).
+ */
+int pgn_cfg_ddim_step(const void* eps_uncond, const void* eps_text, int eps_dtype, const void* sample,
+                      void* prev_sample, void* pred_x0, int sample_dtype, int64_t numel, float guidance,
+                      float sqrt_alpha_t, float sqrt_beta_t, float sqrt_alpha_prev, float dir_coef,
+                      int prediction_type, unsigned flags, float clip_range, void* stream);
+
+/* Fused CFG combine + Euler step (diffusers 0.27.2 EulerDiscreteScheduler.step with gamma = 0):
+ *   eps = eps_u + g*(eps_t - eps_u);  x0 per prediction type with sigma;  d = (x - x0)/sigma;
+ *   prev = x + d*(sigma_next - sigma)
+ * `sample` (sample_dtype) is the UNSCALED latent and is upcast to fp32 as diffusers does; prev_sample
+ * and pred_x0 are written in out_dtype (diffusers casts back to the eps dtype; PGN_F32 keeps fp32). */
+int pgn_cfg_euler_step(const void* eps_uncond, const void* eps_text, int eps_dtype, const void* sample,
+                       int sample_dtype, void* prev_sample, void* pred_x0, int out_dtype, int64_t numel,
+                       float guidance, float sigma, float sigma_next, int prediction_type, unsigned flags,
+                       void* stream);
+
+/* `torch.cat([latents]*2)` + scheduler.scale_model_input + the cast conv_in's autocast performs
+ * (lavit_for_pigeon.py:747-748): out[0:numel] = out[numel:2*numel] = cast(latents / divisor).
+ * divisor = 1 for DDIM, sqrt(sigma^2+1) for Euler. */
+int pgn_cfg_expand_scale(const void* latents, int in_dtype, void* out, int out_dtype, int64_t numel,
+                         float divisor, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU), NCHW contiguous.  Replaces the GroupNorm -> SiLU pairs inside
+ * diffusers ResnetBlock2D / conv_norm_out and the plain GroupNorm of Transformer2DModel.norm,
+ * reached through `self.unet(...)` at lavit_for_pigeon.py:752-757 (torch.nn.functional.group_norm
+ * run in fp32 by autocast, then F.silu, then the bf16 cast of the following conv).
+ * x, y: [N, C, HW]; gamma/beta: affine_dtype [C] (may both be NULL = no affine); C % G == 0.
+ * Statistics and arithmetic in fp32, one rounding to y_dtype at the end.
+ * act: 0 = none, 1 = SiLU.  Algorithmic bytes: numel*(sizeof x + sizeof y).
+ */
+int pgn_groupnorm_silu(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma, const void* beta,
+                       int affine_dtype, int N, int C, int HW, int G, float eps, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head attention forward, softmax(q k^T * scale + key_bias) v, flash-style on MFMA.
+ * Replaces xformers.ops.memory_efficient_attention(q, k, v, attn_bias, scale) as called by diffusers
+ * XFormersAttnProcessor (enabled at lavit_for_pigeon.py:202) — self- and cross-attention.
+ *
+ * q [B, Nq, H, D], k/v [B, Nk, H, D], out [B, Nq, H, D]; last dim contiguous, the other three given
+ * as ELEMENT strides (batch, sequence, head), so the [B, N, H*D] output of to_q/to_k/to_v is read in
+ * place (no head_to_batch_dim copy).  dtype: PGN_BF16 or PGN_F16 storage, fp32 softmax/accumulate.
+ * key_bias: fp32 [B, Nk] additive bias broadcast over heads and queries (key padding:
+ * lavit_for_pigeon.py:873-874 lowres path; modeling_decoder.py:100-102), or NULL.
+ * Any Nq, Nk >= 1 (ragged tails handled); D in {64} this round, others -> PGN_ERR_UNSUPPORTED.
+ * Algorithmic work: 4*B*H*Nq*Nk*D flop.
+ */
+int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H, int Nq,
+                      int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn,
+                      int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
+                      int64_t o_sh, const float* key_bias, int64_t bias_sb, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIGEON_HIP_H */

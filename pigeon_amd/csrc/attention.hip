@@ -1,0 +1,310 @@
+// Flash-style multi-head attention forward on gfx950 MFMA (see include/pigeon_hip.h: pgn_attention_fwd).
+// Replaces xformers.ops.memory_efficient_attention as reached from diffusers XFormersAttnProcessor
+// (enabled at Pigeon/models/lavit_for_pigeon.py:202): softmax(q k^T * scale [+ key bias]) v, head_dim 64.
+//
+// Structure (MI355X-first, not a warp-shaped port):
+//   * one 512-thread workgroup (8 wave64, 2 per SIMD) owns 256 query rows of one (batch, head); each wave
+//     owns 32 rows.  Workgroup ids are remapped so that all query tiles of a head run on one XCD and its
+//     K/V (<= 1 MiB) stay in that XCD's L2.
+//   * K/V stream through LDS in 64-key tiles, double-buffered, register-staged: the global loads of
+//     tile t+1 are issued before the MFMAs of tile t and written to LDS after them (one barrier per tile).
+//   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (keys on the accumulator rows, the query on the lane), so
+//     every lane owns one query row: row max / sum are lane-local plus ONE permlane32 swap, and the
+//     accumulator registers are already the B operand of O^T = V^T P^T (no LDS round trip for P).
+//   * K tile is XOR-swizzled for conflict-free ds_read_b128; V tile is laid out in 8-key x 32-dim
+//     sub-tiles and read with ds_read_b64_tr_b16 (hardware transpose) as the A operand.
+//   * q/k/v/out are addressed through (batch, sequence, head) element strides: the [B, N, H*64] output
+//     of to_q/to_k/to_v is consumed in place, no head_to_batch_dim copy.
+#include "pgn_common.h"
+
+namespace {
+
+constexpr int ATT_D = 64;
+constexpr int ATT_BM = 256;      // query rows per workgroup
+constexpr int ATT_BN = 64;       // keys per tile
+constexpr int ATT_THREADS = 512;
+constexpr int ATT_TILE_ELEMS = ATT_BN * ATT_D;  // 4096 x 16-bit = 8 KiB
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+struct AttnArgs {
+    const unsigned short* q;
+    const unsigned short* k;
+    const unsigned short* v;
+    unsigned short* o;
+    const float* bias;
+    int H, Nq, Nk, nqt;
+    long long q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh, bias_sb;
+    float c;  // scale * log2(e)
+};
+
+template <int DT>
+__device__ __forceinline__ f32x16_t mfma32(u16x8_t a, u16x8_t b, f32x16_t c) {
+    if constexpr (DT == PGN_BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                       c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c,
+                                                      0, 0, 0);
+}
+
+__device__ __forceinline__ float xhalf_max(float x) {
+    // max over the two 32-lane halves (lane l <-> lane l^32)
+    const unsigned u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// LDS byte offsets of 16-byte chunk `ch` (0..7) of key row `row` (0..63)
+__device__ __forceinline__ int k_lds_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int v_lds_off(int row, int ch) {
+    return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * (ch & 3);
+}
+
+template <int DT, bool HAS_BIAS>
+__global__ __launch_bounds__(ATT_THREADS) void pgn_attn_fwd_d64_kernel(AttnArgs a) {
+    // [buf][K|V][8 KiB] + [buf][64 floats of key bias]; one object so the base stays 16-byte aligned
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * ATT_TILE_ELEMS * 2 + 2 * ATT_BN * 4];
+    float* bias_lds = reinterpret_cast<float*>(smem + 2 * 2 * ATT_TILE_ELEMS * 2);
+
+    // XCD-aware bijective remap: consecutive logical ids (same head) share blockIdx % 8, i.e. one XCD
+    const unsigned nwg = gridDim.x, orig = blockIdx.x;
+    const unsigned xcd = orig & 7u, qd = nwg >> 3, rm = nwg & 7u;
+    const unsigned wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    const int bh = (int)(wgid / (unsigned)a.nqt), qt = (int)(wgid % (unsigned)a.nqt);
+    const int b = bh / a.H, h = bh % a.H;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[row][16 s + 8 hh + j]
+    const int qrow = qt * ATT_BM + wid * 32 + l31;
+    const int qrow_c = qrow < a.Nq ? qrow : a.Nq - 1;
+    const unsigned short* qp = a.q + b * a.q_sb + (long long)qrow_c * a.q_sn + h * a.q_sh + 8 * hh;
+    u16x8_t qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const u16x8_t*>(qp + 16 * s);
+
+    // ---- staging assignment: thread -> (key row, 16-byte chunk) of the K and V tiles
+    const int srow = tid >> 3, sch = tid & 7;
+    const unsigned short* kp = a.k + b * a.k_sb + h * a.k_sh + sch * 8;
+    const unsigned short* vp = a.v + b * a.v_sb + h * a.v_sh + sch * 8;
+    const int k_woff = k_lds_off(srow, sch), v_woff = v_lds_off(srow, sch);
+    const float* bp = HAS_BIAS ? a.bias + b * a.bias_sb : nullptr;
+
+    const int nt = (a.Nk + ATT_BN - 1) / ATT_BN;
+    const u16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    u16x8_t kreg, vreg;
+    float breg = 0.f;
+    auto stage_load = [&](int t) {
+        const int key = t * ATT_BN + srow;
+        if (key < a.Nk) {
+            kreg = *reinterpret_cast<const u16x8_t*>(kp + (long long)key * a.k_sn);
+            vreg = *reinterpret_cast<const u16x8_t*>(vp + (long long)key * a.v_sn);
+        } else {
+            kreg = zero8;
+            vreg = zero8;
+        }
+        if constexpr (HAS_BIAS) {
+            if (tid < ATT_BN) {
+                const int kk = t * ATT_BN + tid;
+                breg = kk < a.Nk ? bp[kk] * 1.4426950408889634f : -INFINITY;
+            }
+        }
+    };
+    auto stage_write = [&](int buf) {
+        unsigned char* base = smem + buf * (2 * ATT_TILE_ELEMS * 2);
+        *reinterpret_cast<u16x8_t*>(base + k_woff) = kreg;
+        *reinterpret_cast<u16x8_t*>(base + ATT_TILE_ELEMS * 2 + v_woff) = vreg;
+        if constexpr (HAS_BIAS) {
+            if (tid < ATT_BN) bias_lds[buf * ATT_BN + tid] = breg;
+        }
+    };
+
+    // ---- per-lane read offsets
+    // K (A operand of S^T): row = kb*32 + l31, chunk = 2 s + hh
+    int k_roff[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) k_roff[kb][s] = k_lds_off(kb * 32 + l31, 2 * s + hh);
+    // V (A operand of O^T = V^T P^T) through ds_read_b64_tr_b16: lane i of a 16-lane group supplies
+    // row (i>>2), columns 4*(i&3).. of the group's 4-key x 16-dim block
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int v_lane_off = 64 * (i16 >> 2) + 32 * g16 + 8 * (i16 & 3);
+
+    f32x16_t oacc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float m_run = -1.0e30f;  // running max (raw score units without bias, exp2 units with bias)
+    float l_run = 0.f;       // this lane's half of the running denominator
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) stage_load(t + 1);
+
+        const unsigned char* kt = smem + buf * (2 * ATT_TILE_ELEMS * 2);
+        const unsigned char* vt = kt + ATT_TILE_ELEMS * 2;
+
+        // ---- S^T = K Q^T : sacc[kb][r] = S[q = l31][key = kb*32 + (r&3) + 8*(r>>2) + 4*hh]
+        f32x16_t sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const u16x8_t kf = *reinterpret_cast<const u16x8_t*>(kt + k_roff[kb][s]);
+                sacc[kb] = mfma32<DT>(kf, qf[s], sacc[kb]);
+            }
+        }
+
+        // ---- scores in exp2 units / masking
+        if constexpr (HAS_BIAS) {
+            const float* bl = bias_lds + buf * ATT_BN;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sacc[kb][r] = fmaf(sacc[kb][r], a.c, bl[kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh]);
+        } else {
+            if (t == nt - 1 && (a.Nk & (ATT_BN - 1)) != 0) {
+                const int rem = a.Nk - t * ATT_BN;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= rem) sacc[kb][r] = -INFINITY;
+            }
+        }
+
+        // ---- online softmax (one query row per lane; the two lane halves hold disjoint keys)
+        float tmax = sacc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kb][r]);
+        tmax = xhalf_max(tmax);
+        const float m_new = fmaxf(m_run, tmax);
+        const float cm = HAS_BIAS ? 1.0f : a.c;
+        if (__any(m_new != m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cm);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * cm;
+        float lsum = 0.f;
+        u16x8_t pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p;
+                if constexpr (HAS_BIAS)
+                    p = __builtin_amdgcn_exp2f(sacc[kb][r] - mc);
+                else
+                    p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], a.c, -mc));
+                lsum += p;
+                pf[kb][r >> 3][r & 7] = Cvt<DT>::from_f32(p);
+            }
+        l_run += lsum;
+
+        // ---- O^T += V^T P^T : A operand element j of lane half hh is key 16 s2 + 8 (j>>2) + 4 hh + (j&3)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int key0 = kb * 32 + 16 * s2 + 4 * hh;  // multiple of 4; +8 for the upper 4 elements
+                    const int off0 = 1024 * (key0 >> 3) + 64 * (key0 & 7) + 512 * d + v_lane_off;
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(vt + off0));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(vt + off0 + 1024));
+                    u16x8_t vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    oacc[d] = mfma32<DT>(vf, pf[kb][s2], oacc[d]);
+                }
+            }
+        }
+
+        if (t + 1 < nt) stage_write(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise and store (lane owns row qrow; 4 consecutive dims per 8-byte store)
+    const float l_tot = xhalf_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    if (qrow < a.Nq) {
+        unsigned short* op = a.o + b * a.o_sb + (long long)qrow * a.o_sn + h * a.o_sh;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u16x4_t w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = Cvt<DT>::from_f32(oacc[d][4 * g4 + j] * inv);
+                *reinterpret_cast<u16x4_t*>(op + d * 32 + 8 * g4 + 4 * hh) = w;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H,
+                                 int Nq, int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb,
+                                 int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb,
+                                 int64_t o_sn, int64_t o_sh, const float* key_bias, int64_t bias_sb, float scale,
+                                 void* stream) {
+    if (q == nullptr || k == nullptr || v == nullptr || out == nullptr) return PGN_ERR_INVALID;
+    if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || D <= 0) return PGN_ERR_INVALID;
+    if (dtype != PGN_BF16 && dtype != PGN_F16) return PGN_ERR_UNSUPPORTED;
+    if (D != ATT_D) return PGN_ERR_UNSUPPORTED;
+    // 16-byte vector loads of q/k/v rows, 8-byte stores of out rows
+    const int64_t st[12] = {q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh};
+    for (int i = 0; i < 12; ++i)
+        if (st[i] < 0 || (st[i] & 7) != 0) return PGN_ERR_INVALID;
+    if (!pgn_aligned(q, 16) || !pgn_aligned(k, 16) || !pgn_aligned(v, 16) || !pgn_aligned(out, 16)) return PGN_ERR_INVALID;
+    if (key_bias != nullptr && bias_sb < 0) return PGN_ERR_INVALID;
+    const long long nqt = (Nq + ATT_BM - 1) / ATT_BM;
+    const long long blocks = (long long)B * H * nqt;
+    if (blocks > 0x7fffffffLL) return PGN_ERR_UNSUPPORTED;
+
+    AttnArgs a;
+    a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
+    a.o = (unsigned short*)out; a.bias = key_bias;
+    a.H = H; a.Nq = Nq; a.Nk = Nk; a.nqt = (int)nqt;
+    a.q_sb = q_sb; a.q_sn = q_sn; a.q_sh = q_sh; a.k_sb = k_sb; a.k_sn = k_sn; a.k_sh = k_sh;
+    a.v_sb = v_sb; a.v_sn = v_sn; a.v_sh = v_sh; a.o_sb = o_sb; a.o_sn = o_sn; a.o_sh = o_sh; a.bias_sb = bias_sb;
+    a.c = scale * 1.4426950408889634f;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)blocks), block(ATT_THREADS);
+    if (dtype == PGN_BF16) {
+        if (key_bias != nullptr) hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<PGN_BF16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<PGN_BF16, false>), grid, block, 0, s, a);
+    } else {
+        if (key_bias != nullptr) hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<PGN_F16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<PGN_F16, false>), grid, block, 0, s, a);
+    }
+    PGN_LAUNCH_CHECK();
+    return PGN_OK;
+}

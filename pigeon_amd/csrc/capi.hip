@@ -1,0 +1,17 @@
+// Version / error-string / workspace entry points of libpigeon_hip (see include/pigeon_hip.h).
+#include "pgn_common.h"
+
+extern "C" int pgn_version(void) { return PGN_VERSION; }
+
+extern "C" const char* pgn_error_string(int code) {
+    if (code == PGN_OK) return "ok";
+    if (code == PGN_ERR_INVALID) return "invalid argument (null pointer, bad size/enum or misaligned buffer)";
+    if (code == PGN_ERR_UNSUPPORTED) return "request not covered by the gfx950 kernels";
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown pigeon_hip error";
+}
+
+extern "C" size_t pgn_workspace_bytes(int op) {
+    (void)op;  // no entry point needs scratch memory: every kernel works in registers / LDS
+    return 0;
+}

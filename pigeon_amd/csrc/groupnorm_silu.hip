@@ -1,0 +1,334 @@
+// GroupNorm (+SiLU), NCHW contiguous (see include/pigeon_hip.h: pgn_groupnorm_silu).
+// Replaces F.group_norm (fp32 under autocast) -> F.silu -> bf16 cast inside diffusers ResnetBlock2D /
+// Transformer2DModel.norm / conv_norm_out, reached from Pigeon/models/lavit_for_pigeon.py:752-757.
+//
+// HBM-bound.  A (sample, group) is one contiguous run of (C/G)*HW elements, so one 1024-thread
+// workgroup owns one group and every access is a 16-byte-per-lane coalesced stream.
+//   resident path : the whole group is held in VGPRs (<= 16 x 8 elements per lane = 128 Ki elements),
+//                   exact two-pass statistics (mean, then centred variance), ONE HBM read + ONE write.
+//   streaming path: groups that do not fit are read twice; the second read follows the first by at most
+//                   one group (<= ~1 MiB per CU) and is served by L2 / Infinity Cache.  Pivot-shifted
+//                   sum / sum-of-squares statistics.
+// Reductions are wavefront-wide (64-lane shuffles) then across the 16 waves through LDS.
+#include "pgn_common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 1024;
+constexpr int GN_WAVES = GN_THREADS / PGN_WAVE;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Sum over the workgroup, result broadcast to every thread.  `slot` selects a private LDS row so that
+// consecutive reductions need only one barrier each.
+__device__ __forceinline__ float block_sum(float v, float* red, int slot) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) red[slot * GN_WAVES + wid] = v;
+    __syncthreads();
+    float t = (lane < GN_WAVES) ? red[slot * GN_WAVES + lane] : 0.f;
+#pragma unroll
+    for (int off = GN_WAVES / 2; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    return __shfl(t, 0);
+}
+
+// Raw register image of 8 consecutive elements: 4 VGPRs for 16-bit storage, 8 for fp32.
+template <int DT>
+struct Raw8 {
+    u16x8_t v;
+};
+template <>
+struct Raw8<PGN_F32> {
+    float f[8];
+};
+
+template <int DT>
+__device__ __forceinline__ Raw8<DT> ld_raw(const void* p, size_t elem) {
+    Raw8<DT> r;
+    if constexpr (DT == PGN_F32) {
+        const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + elem);
+        const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + elem + 4);
+        r.f[0] = a.x; r.f[1] = a.y; r.f[2] = a.z; r.f[3] = a.w; r.f[4] = b.x; r.f[5] = b.y; r.f[6] = b.z; r.f[7] = b.w;
+    } else {
+        r.v = *reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(p) + elem);
+    }
+    return r;
+}
+// Make the register image opaque to the optimiser: without this hipcc keeps the fp32 copies of pass 1
+// alive across the reductions (8 VGPRs per vector instead of 4) and the 16-vector kernel spills.
+template <int DT>
+__device__ __forceinline__ void pin_raw(Raw8<DT>& r) {
+    if constexpr (DT == PGN_F32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(r.f[j]));
+    } else {
+        asm volatile("" : "+v"(r.v));
+    }
+}
+template <int DT>
+__device__ __forceinline__ void raw_to_f32(const Raw8<DT>& r, float (&f)[8]) {
+    if constexpr (DT == PGN_F32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = r.f[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = Cvt<DT>::to_f32(r.v[j]);
+    }
+}
+template <int DT>
+__device__ __forceinline__ void ld8(const void* p, size_t elem, float (&f)[8]) {
+    raw_to_f32<DT>(ld_raw<DT>(p, elem), f);
+}
+template <int DT>
+__device__ __forceinline__ void st8(void* p, size_t elem, const float (&f)[8]) {
+    if constexpr (DT == PGN_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + elem) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + elem + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    } else {
+        u16x8_t t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = Cvt<DT>::from_f32(f[j]);
+        *reinterpret_cast<u16x8_t*>(reinterpret_cast<unsigned short*>(p) + elem) = t;
+    }
+}
+
+__device__ __forceinline__ float load_affine(const void* p, int adt, int c, float dflt) {
+    if (p == nullptr) return dflt;
+    if (adt == PGN_F32) return reinterpret_cast<const float*>(p)[c];
+    const unsigned short h = reinterpret_cast<const unsigned short*>(p)[c];
+    return adt == PGN_BF16 ? Cvt<PGN_BF16>::to_f32(h) : Cvt<PGN_F16>::to_f32(h);
+}
+
+__device__ __forceinline__ float silu_f32(float v) {
+    // v * sigmoid(v); exp via v_exp_f32 (exp2), reciprocal via v_rcp_f32 (<= 1 ulp each)
+    const float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+struct GnArgs {
+    const void* x;
+    void* y;
+    const void* gamma;
+    const void* beta;
+    int adt;
+    int cpg;   // channels per group
+    int HW;
+    int G;
+    unsigned group_elems;
+    float eps;
+    int act;
+};
+
+// normalise 8 consecutive elements starting at in-group element index e0 and store
+template <int YDT, bool UNIFORM_CH>
+__device__ __forceinline__ void norm_store8(const GnArgs& a, size_t base, unsigned e0, int ch0, float (&f)[8],
+                                            float mean, float rstd) {
+    if constexpr (UNIFORM_CH) {
+        const int c = ch0 + (int)(e0 / (unsigned)a.HW);
+        const float ga = load_affine(a.gamma, a.adt, c, 1.f) * rstd;
+        const float be = load_affine(a.beta, a.adt, c, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = (f[j] - mean) * ga + be;
+            f[j] = a.act ? silu_f32(v) : v;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = ch0 + (int)((e0 + j) / (unsigned)a.HW);
+            const float ga = load_affine(a.gamma, a.adt, c, 1.f) * rstd;
+            const float be = load_affine(a.beta, a.adt, c, 0.f);
+            float v = (f[j] - mean) * ga + be;
+            f[j] = a.act ? silu_f32(v) : v;
+        }
+    }
+    st8<YDT>(a.y, base + e0, f);
+}
+
+// ---- resident path: R vectors of 8 elements per lane stay in registers -------------------------
+template <int XDT, int YDT, int R, bool UNIFORM_CH>
+__global__ __launch_bounds__(GN_THREADS) void pgn_gn_resident_kernel(GnArgs a) {
+    __shared__ float red[2 * GN_WAVES];
+    const unsigned nvec = a.group_elems >> 3;
+    const size_t base = (size_t)blockIdx.x * a.group_elems;
+    const int ch0 = (int)(blockIdx.x % (unsigned)a.G) * a.cpg;
+    const unsigned tid = threadIdx.x;
+
+    Raw8<XDT> raw[R];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned v = tid + (unsigned)r * GN_THREADS;
+        if (v < nvec) {
+            raw[r] = ld_raw<XDT>(a.x, base + ((size_t)v << 3));
+            float f[8];
+            raw_to_f32<XDT>(raw[r], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += f[j];
+        }
+    }
+    const float inv_n = 1.0f / (float)a.group_elems;
+    const float mean = block_sum(s, red, 0) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned v = tid + (unsigned)r * GN_THREADS;
+        if (v < nvec) {
+            float f[8];
+            pin_raw<XDT>(raw[r]);
+            raw_to_f32<XDT>(raw[r], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = f[j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float var = block_sum(q, red, 1) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned v = tid + (unsigned)r * GN_THREADS;
+        if (v < nvec) {
+            float f[8];
+            pin_raw<XDT>(raw[r]);
+            raw_to_f32<XDT>(raw[r], f);
+            norm_store8<YDT, UNIFORM_CH>(a, base, v << 3, ch0, f, mean, rstd);
+        }
+    }
+}
+
+// ---- streaming path: two reads (second from cache), any group size, 8-element vectors ----------
+template <int XDT, int YDT, bool UNIFORM_CH>
+__global__ __launch_bounds__(GN_THREADS) void pgn_gn_stream_kernel(GnArgs a) {
+    __shared__ float red[2 * GN_WAVES];
+    const unsigned nvec = a.group_elems >> 3;
+    const size_t base = (size_t)blockIdx.x * a.group_elems;
+    const int ch0 = (int)(blockIdx.x % (unsigned)a.G) * a.cpg;
+    const unsigned tid = threadIdx.x;
+
+    const float pivot = Cvt<XDT>::to_f32(reinterpret_cast<const typename Cvt<XDT>::storage*>(a.x)[base]);
+    float s = 0.f, q = 0.f;
+    for (unsigned v = tid; v < nvec; v += GN_THREADS) {
+        float f[8];
+        ld8<XDT>(a.x, base + ((size_t)v << 3), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = f[j] - pivot;
+            s += d;
+            q += d * d;
+        }
+    }
+    const float inv_n = 1.0f / (float)a.group_elems;
+    const float ms = block_sum(s, red, 0) * inv_n;  // mean - pivot
+    const float mq = block_sum(q, red, 1) * inv_n;
+    const float mean = pivot + ms;
+    const float var = fmaxf(mq - ms * ms, 0.f);
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    // walk back-to-front: the most recently read lines are the likeliest to still be in L2
+    for (unsigned it = 0; it * GN_THREADS < nvec; ++it) {
+        const unsigned blk = (nvec - 1) / GN_THREADS - it;
+        const unsigned v = blk * GN_THREADS + tid;
+        if (v < nvec) {
+            float f[8];
+            ld8<XDT>(a.x, base + ((size_t)v << 3), f);
+            norm_store8<YDT, UNIFORM_CH>(a, base, v << 3, ch0, f, mean, rstd);
+        }
+    }
+}
+
+// ---- scalar path: group_elems not a multiple of 8 (or unaligned) -------------------------------
+template <int XDT, int YDT>
+__global__ __launch_bounds__(GN_THREADS) void pgn_gn_scalar_kernel(GnArgs a) {
+    __shared__ float red[2 * GN_WAVES];
+    typedef typename Cvt<XDT>::storage XS;
+    typedef typename Cvt<YDT>::storage YS;
+    const size_t base = (size_t)blockIdx.x * a.group_elems;
+    const int ch0 = (int)(blockIdx.x % (unsigned)a.G) * a.cpg;
+    const XS* x = reinterpret_cast<const XS*>(a.x) + base;
+    YS* y = reinterpret_cast<YS*>(a.y) + base;
+    const float pivot = Cvt<XDT>::to_f32(x[0]);
+    float s = 0.f, q = 0.f;
+    for (unsigned i = threadIdx.x; i < a.group_elems; i += GN_THREADS) {
+        const float d = Cvt<XDT>::to_f32(x[i]) - pivot;
+        s += d;
+        q += d * d;
+    }
+    const float inv_n = 1.0f / (float)a.group_elems;
+    const float ms = block_sum(s, red, 0) * inv_n;
+    const float mq = block_sum(q, red, 1) * inv_n;
+    const float mean = pivot + ms;
+    const float var = fmaxf(mq - ms * ms, 0.f);
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    for (unsigned i = threadIdx.x; i < a.group_elems; i += GN_THREADS) {
+        const int c = ch0 + (int)(i / (unsigned)a.HW);
+        const float ga = load_affine(a.gamma, a.adt, c, 1.f) * rstd;
+        const float be = load_affine(a.beta, a.adt, c, 0.f);
+        float v = (Cvt<XDT>::to_f32(x[i]) - mean) * ga + be;
+        y[i] = Cvt<YDT>::from_f32(a.act ? silu_f32(v) : v);
+    }
+}
+
+template <int XDT, int YDT, bool U>
+int launch_vec(const GnArgs& a, int blocks, hipStream_t s) {
+    const unsigned nvec = a.group_elems >> 3;
+    const unsigned per_thread = (nvec + GN_THREADS - 1) / GN_THREADS;
+    const unsigned max_r = (XDT == PGN_F32) ? 8u : 16u;
+    const dim3 grid(blocks), block(GN_THREADS);
+    if (per_thread <= 2)
+        hipLaunchKernelGGL((pgn_gn_resident_kernel<XDT, YDT, 2, U>), grid, block, 0, s, a);
+    else if (per_thread <= 4)
+        hipLaunchKernelGGL((pgn_gn_resident_kernel<XDT, YDT, 4, U>), grid, block, 0, s, a);
+    else if (per_thread <= 8)
+        hipLaunchKernelGGL((pgn_gn_resident_kernel<XDT, YDT, 8, U>), grid, block, 0, s, a);
+    else if (per_thread <= 16 && max_r >= 16) {
+        if constexpr (XDT != PGN_F32)
+            hipLaunchKernelGGL((pgn_gn_resident_kernel<XDT, YDT, 16, U>), grid, block, 0, s, a);
+    } else
+        hipLaunchKernelGGL((pgn_gn_stream_kernel<XDT, YDT, U>), grid, block, 0, s, a);
+    return 0;
+}
+
+template <int XDT, int YDT>
+int launch_dt(const GnArgs& a, int blocks, bool vec_ok, hipStream_t s) {
+    if (!vec_ok) {
+        hipLaunchKernelGGL((pgn_gn_scalar_kernel<XDT, YDT>), dim3(blocks), dim3(GN_THREADS), 0, s, a);
+        return 0;
+    }
+    if ((a.HW & 7) == 0) return launch_vec<XDT, YDT, true>(a, blocks, s);
+    return launch_vec<XDT, YDT, false>(a, blocks, s);
+}
+
+}  // namespace
+
+extern "C" int pgn_groupnorm_silu(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma,
+                                  const void* beta, int affine_dtype, int N, int C, int HW, int G, float eps,
+                                  int act, void* stream) {
+    if (x == nullptr || y == nullptr) return PGN_ERR_INVALID;
+    if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return PGN_ERR_INVALID;
+    if (pgn_dtype_size(x_dtype) == 0 || pgn_dtype_size(y_dtype) == 0) return PGN_ERR_INVALID;
+    if ((gamma != nullptr || beta != nullptr) && pgn_dtype_size(affine_dtype) == 0) return PGN_ERR_INVALID;
+    if (act != 0 && act != 1) return PGN_ERR_INVALID;
+    if (!(eps >= 0.f)) return PGN_ERR_INVALID;
+    const int cpg = C / G;
+    const long long ge = (long long)cpg * HW;
+    if (ge > 0x7fffffffLL || (long long)N * G > 0x7fffffffLL) return PGN_ERR_UNSUPPORTED;
+    GnArgs a;
+    a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.adt = affine_dtype; a.cpg = cpg; a.HW = HW; a.G = G;
+    a.group_elems = (unsigned)ge; a.eps = eps; a.act = act;
+    const int blocks = N * G;
+    const bool vec_ok = (ge % 8 == 0) && pgn_aligned(x, 16) && pgn_aligned(y, 16);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == PGN_BF16 && y_dtype == PGN_BF16) launch_dt<PGN_BF16, PGN_BF16>(a, blocks, vec_ok, s);
+    else if (x_dtype == PGN_F16 && y_dtype == PGN_F16) launch_dt<PGN_F16, PGN_F16>(a, blocks, vec_ok, s);
+    else if (x_dtype == PGN_F32 && y_dtype == PGN_F32) launch_dt<PGN_F32, PGN_F32>(a, blocks, vec_ok, s);
+    else if (x_dtype == PGN_BF16 && y_dtype == PGN_F32) launch_dt<PGN_BF16, PGN_F32>(a, blocks, vec_ok, s);
+    else if (x_dtype == PGN_F32 && y_dtype == PGN_BF16) launch_dt<PGN_F32, PGN_BF16>(a, blocks, vec_ok, s);
+    else return PGN_ERR_UNSUPPORTED;
+    PGN_LAUNCH_CHECK();
+    return PGN_OK;
+}

@@ -1,0 +1,284 @@
+"""Tensor-level entry points over the C ABI (include/pigeon_hip.h).
+
+Every function takes CUDA(HIP) tensors, enqueues on torch's current stream and returns torch tensors
+allocated through torch's caching allocator.  Nothing here computes on the CPU and nothing falls back to
+a PyTorch implementation: non-device tensors or unsupported shapes raise.
+"""
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib
+from ._lib import (PGN_BF16, PGN_F16, PGN_F32, PGN_PRED_EPSILON, PGN_PRED_SAMPLE, PGN_PRED_V,
+                   PGN_STEP_CLIP_SAMPLE, PGN_STEP_FUSED_FP32, PGN_STEP_USE_CLIPPED_OUTPUT)
+
+_DT = {torch.float32: PGN_F32, torch.bfloat16: PGN_BF16, torch.float16: PGN_F16}
+_PRED = {"epsilon": PGN_PRED_EPSILON, "sample": PGN_PRED_SAMPLE, "v_prediction": PGN_PRED_V}
+
+# Codebook ids start after the 32000 text ids + 2 specials (lavit_for_pigeon.py:905)
+LAVIT_ID_OFFSET = 32002
+LAVIT_MAX_TOKENS = 256  # lavit_for_pigeon.py:907-908
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"pigeon_amd: unsupported dtype {t.dtype}") from None
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pigeon_amd ops run on the MI355X only: got a non-device tensor (no CPU fallback)")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+# optional per-launch timing hook used by bench.py: callable(kind:str, work:float, fn) -> result
+_timer = None
+
+
+def set_launch_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def _launch(kind, work, fn):
+    if _timer is None:
+        return fn()
+    return _timer(kind, work, fn)
+
+
+# ------------------------------------------------------------------------------------------------
+def token_gather(image_tokens: Union[Sequence[torch.Tensor], torch.Tensor], codebook: torch.Tensor,
+                 out_dtype: torch.dtype = torch.bfloat16, id_offset: int = LAVIT_ID_OFFSET,
+                 max_tokens: int = LAVIT_MAX_TOKENS, pad_len: Optional[int] = None, packed: bool = True,
+                 padded: bool = True, check: bool = False):
+    """Fused replacement of generate_image_embeds' id filter + F.embedding + cast (lavit_for_pigeon.py:903-918)
+    and of HighresVQDecoder's pad/mask loop (modeling_decoder.py:310-317).
+
+    image_tokens: list of 1-D int64 device tensors (ragged) or one [B, L] int64 tensor.
+    Returns dict(token_nums int64 [B], packed [sum_worstcase, dim] (rows past sum(token_nums) are
+    unspecified), padded [B, pad_len, dim], mask [B, pad_len]).  No host sync unless check=True.
+    """
+    lib = _lib.load()
+    if isinstance(image_tokens, torch.Tensor):
+        if image_tokens.dim() != 2:
+            raise ValueError("image_tokens tensor must be [B, L]")
+        B, L = image_tokens.shape
+        ids = image_tokens.contiguous().view(-1)
+        lens = [L] * B
+    else:
+        B = len(image_tokens)
+        lens = [int(t.numel()) for t in image_tokens]
+        ids = torch.cat([t.reshape(-1) for t in image_tokens]) if B else torch.empty(0, dtype=torch.int64)
+    _dev(ids, codebook)
+    if ids.dtype != torch.int64:
+        raise TypeError("image_tokens must be int64")
+    if codebook.dtype != torch.float32 or codebook.dim() != 2:
+        raise TypeError("codebook must be fp32 [num_codes, dim]")
+    codebook = codebook.contiguous()
+    dev = codebook.device
+    num_codes, dim = codebook.shape
+    offs, acc = [0], 0
+    for n in lens:
+        acc += n
+        offs.append(acc)
+    offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    pad_len = max_tokens if pad_len is None else pad_len
+    worst = sum(min(n, max_tokens) for n in lens)
+    token_nums = torch.empty(B, dtype=torch.int64, device=dev)
+    out_packed = torch.empty(worst, dim, dtype=out_dtype, device=dev) if packed else None
+    out_padded = torch.empty(B, pad_len, dim, dtype=out_dtype, device=dev) if padded else None
+    out_mask = torch.empty(B, pad_len, dtype=out_dtype, device=dev) if padded else None
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    work = 200.0 * worst  # algorithmic bytes: 8 B id + 128 B row + 64 B bf16 row per token
+
+    def run():
+        rc = lib.pgn_token_gather(_ptr(ids), _ptr(offsets), B, _ptr(codebook), num_codes, dim, id_offset, max_tokens,
+                                  _DT[out_dtype], _ptr(token_nums), _ptr(out_packed), _ptr(out_padded), _ptr(out_mask),
+                                  pad_len, _ptr(status), _stream())
+        _lib.check(rc, "pgn_token_gather")
+
+    _launch("gather", work, run)
+    if check and int(status.item()) != 0:
+        raise IndexError("token_gather: a kept token id is outside the codebook (F.embedding would raise)")
+    return {"token_nums": token_nums, "packed": out_packed, "padded": out_padded, "mask": out_mask, "status": status}
+
+
+# ------------------------------------------------------------------------------------------------
+def cfg_ddim_step(noise_pred: Optional[torch.Tensor], sample: torch.Tensor, guidance_scale: float,
+                  sqrt_alpha_t: float, sqrt_beta_t: float, sqrt_alpha_prev: float, dir_coef: float,
+                  prediction_type: str = "epsilon", eps_uncond: Optional[torch.Tensor] = None,
+                  eps_text: Optional[torch.Tensor] = None, clip_sample_range: Optional[float] = None,
+                  use_clipped_model_output: bool = False, fused_fp32: bool = False, return_pred_x0: bool = False,
+                  out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """chunk(2) + guidance + DDIMScheduler.step (lavit_for_pigeon.py:760-764) in one launch.
+
+    noise_pred: [2B, ...] (uncond first, text second) — or pass eps_uncond / eps_text separately
+    (eps_uncond=None means "no guidance").  sample: [B, ...] latents (fp32 in the reference).
+    """
+    lib = _lib.load()
+    if noise_pred is not None:
+        half = noise_pred.shape[0] // 2
+        if noise_pred.shape[0] != 2 * sample.shape[0]:
+            raise ValueError("noise_pred must hold [uncond; text] for every latent")
+        noise_pred = noise_pred.contiguous()
+        eps_uncond, eps_text = noise_pred[:half], noise_pred[half:]
+    _dev(eps_uncond, eps_text, sample)
+    eps_text = eps_text.contiguous()
+    eps_uncond = None if eps_uncond is None else eps_uncond.contiguous()
+    sample = sample.contiguous()
+    if eps_text.numel() != sample.numel():
+        raise ValueError("eps and sample sizes differ")
+    prev = torch.empty_like(sample) if out is None else out
+    x0 = torch.empty_like(sample) if return_pred_x0 else None
+    flags = (PGN_STEP_FUSED_FP32 if fused_fp32 else 0)
+    if clip_sample_range is not None:
+        flags |= PGN_STEP_CLIP_SAMPLE
+        if use_clipped_model_output:
+            flags |= PGN_STEP_USE_CLIPPED_OUTPUT
+    n = sample.numel()
+    es, ss = eps_text.element_size(), sample.element_size()
+    work = float(n * ((2 if eps_uncond is not None else 1) * es + 2 * ss + (ss if x0 is not None else 0)))
+
+    def run():
+        rc = lib.pgn_cfg_ddim_step(_ptr(eps_uncond), _ptr(eps_text), _dt(eps_text), _ptr(sample), _ptr(prev), _ptr(x0),
+                                   _dt(sample), n, float(guidance_scale), float(sqrt_alpha_t), float(sqrt_beta_t),
+                                   float(sqrt_alpha_prev), float(dir_coef), _PRED[prediction_type], flags,
+                                   float(clip_sample_range or 0.0), _stream())
+        _lib.check(rc, "pgn_cfg_ddim_step")
+
+    _launch("cfg_step", work, run)
+    return prev, x0
+
+
+def cfg_euler_step(noise_pred: Optional[torch.Tensor], sample: torch.Tensor, guidance_scale: float, sigma: float,
+                   sigma_next: float, prediction_type: str = "epsilon", eps_uncond: Optional[torch.Tensor] = None,
+                   eps_text: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+                   fused_fp32: bool = False, return_pred_x0: bool = False):
+    """chunk(2) + guidance + EulerDiscreteScheduler.step (gamma = 0) in one launch."""
+    lib = _lib.load()
+    if noise_pred is not None:
+        half = noise_pred.shape[0] // 2
+        if noise_pred.shape[0] != 2 * sample.shape[0]:
+            raise ValueError("noise_pred must hold [uncond; text] for every latent")
+        noise_pred = noise_pred.contiguous()
+        eps_uncond, eps_text = noise_pred[:half], noise_pred[half:]
+    _dev(eps_uncond, eps_text, sample)
+    eps_text = eps_text.contiguous()
+    eps_uncond = None if eps_uncond is None else eps_uncond.contiguous()
+    sample = sample.contiguous()
+    out_dtype = eps_text.dtype if out_dtype is None else out_dtype  # diffusers casts back to model_output.dtype
+    prev = torch.empty(sample.shape, dtype=out_dtype, device=sample.device)
+    x0 = torch.empty_like(prev) if return_pred_x0 else None
+    n = sample.numel()
+    work = float(n * ((2 if eps_uncond is not None else 1) * eps_text.element_size() + sample.element_size()
+                      + prev.element_size() * (2 if x0 is not None else 1)))
+
+    def run():
+        rc = lib.pgn_cfg_euler_step(_ptr(eps_uncond), _ptr(eps_text), _dt(eps_text), _ptr(sample), _dt(sample),
+                                    _ptr(prev), _ptr(x0), _DT[out_dtype], n, float(guidance_scale), float(sigma),
+                                    float(sigma_next), _PRED[prediction_type], PGN_STEP_FUSED_FP32 if fused_fp32 else 0,
+                                    _stream())
+        _lib.check(rc, "pgn_cfg_euler_step")
+
+    _launch("cfg_step", work, run)
+    return prev, x0
+
+
+def cfg_expand_scale(latents: torch.Tensor, out_dtype: torch.dtype, divisor: float = 1.0) -> torch.Tensor:
+    """torch.cat([latents]*2) + scale_model_input + cast (lavit_for_pigeon.py:747-748) in one launch."""
+    lib = _lib.load()
+    _dev(latents)
+    latents = latents.contiguous()
+    out = torch.empty((2 * latents.shape[0],) + tuple(latents.shape[1:]), dtype=out_dtype, device=latents.device)
+    n = latents.numel()
+
+    def run():
+        rc = lib.pgn_cfg_expand_scale(_ptr(latents), _dt(latents), _ptr(out), _DT[out_dtype], n, float(divisor), _stream())
+        _lib.check(rc, "pgn_cfg_expand_scale")
+
+    _launch("cfg_expand", float(n * (latents.element_size() + 2 * out.element_size())), run)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def group_norm_silu(x: torch.Tensor, num_groups: int, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
+                    eps: float = 1e-5, silu: bool = True, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """GroupNorm (+SiLU) on an NCHW-contiguous tensor [N, C, *spatial]; fp32 statistics and arithmetic."""
+    lib = _lib.load()
+    _dev(x, weight, bias)
+    if x.dim() < 2:
+        raise ValueError("group_norm_silu expects [N, C, ...]")
+    x = x.contiguous()
+    N, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (N * C) if N * C else 0
+    if (weight is None) != (bias is None):
+        raise ValueError("weight and bias must both be given or both be None")
+    adt = PGN_F32
+    if weight is not None:
+        if weight.dtype != bias.dtype or weight.numel() != C or bias.numel() != C:
+            raise ValueError("affine parameters must be [C] and share a dtype")
+        weight, bias = weight.contiguous(), bias.contiguous()
+        adt = _dt(weight)
+    y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    work = float(x.numel() * (x.element_size() + y.element_size()))
+
+    def run():
+        rc = lib.pgn_groupnorm_silu(_ptr(x), _dt(x), _ptr(y), _dt(y), _ptr(weight), _ptr(bias), adt, N, C, HW,
+                                    int(num_groups), float(eps), 1 if silu else 0, _stream())
+        _lib.check(rc, "pgn_groupnorm_silu")
+
+    _launch("groupnorm_silu" if silu else "groupnorm", work, run)
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
+              key_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T * scale + key_bias) v per head, replacing xformers.ops.memory_efficient_attention.
+
+    q: [B, Nq, heads*D] (the un-permuted output of to_q), k/v: [B, Nk, heads*D]; any strides as long as the
+    last dim is contiguous.  key_bias: fp32 [B, Nk] additive (key padding) or None.  Returns [B, Nq, heads*D].
+    """
+    lib = _lib.load()
+    _dev(q, k, v, key_bias)
+    if q.dim() != 3 or k.dim() != 3 or v.dim() != 3:
+        raise ValueError("attention expects [B, N, heads*D] tensors")
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    if C % heads or k.shape[2] != C or v.shape[2] != C or v.shape[1] != Nk or k.shape[0] != B or v.shape[0] != B:
+        raise ValueError("attention: inconsistent q/k/v shapes")
+    D = C // heads
+    if not (q.dtype == k.dtype == v.dtype):
+        raise TypeError("attention: q, k, v must share a dtype")
+
+    def fix(t):
+        return t if t.stride(2) == 1 else t.contiguous()
+
+    q, k, v = fix(q), fix(k), fix(v)
+    out = torch.empty(B, Nq, C, dtype=q.dtype, device=q.device)
+    if key_bias is not None:
+        if key_bias.shape != (B, Nk):
+            raise ValueError("key_bias must be [B, Nk]")
+        key_bias = key_bias.to(torch.float32).contiguous()
+    scale = float(D) ** -0.5 if scale is None else float(scale)
+    work = 4.0 * B * heads * Nq * Nk * D
+
+    def run():
+        rc = lib.pgn_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _dt(q), B, heads, Nq, Nk, D,
+                                   q.stride(0), q.stride(1), D, k.stride(0), k.stride(1), D,
+                                   v.stride(0), v.stride(1), D, out.stride(0), out.stride(1), D,
+                                   _ptr(key_bias), Nk if key_bias is not None else 0, scale, _stream())
+        _lib.check(rc, "pgn_attention_fwd")
+
+    _launch("attention", work, run)
+    return out

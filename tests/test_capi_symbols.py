@@ -1,0 +1,54 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/pigeon_hip.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+from pigeon_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "pigeon_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pgn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_documented_entry_points():
+    names = _declared()
+    for must in ("pgn_token_gather", "pgn_cfg_ddim_step", "pgn_cfg_euler_step", "pgn_groupnorm_silu",
+                 "pgn_attention_fwd", "pgn_version", "pgn_workspace_bytes"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "build with make -C pigeon_amd/csrc"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in pigeon_hip.h but not exported"
+
+
+def test_binding_table_matches_header():
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_version_and_error_strings_need_no_gpu():
+    lib = _lib.load()
+    assert lib.pgn_version() == 100
+    assert lib.pgn_error_string(0) == b"ok"
+    assert b"invalid" in lib.pgn_error_string(-1)
+    assert lib.pgn_workspace_bytes(3) == 0
+
+
+def test_argument_validation_happens_before_any_launch():
+    lib = _lib.load()
+    # null pointers / bad sizes are refused on the host, so this is safe without a GPU
+    assert lib.pgn_attention_fwd(None, None, None, None, 1, 1, 1, 1, 1, 64, *([0] * 12), None, 0, 0.125, None) == -1
+    assert lib.pgn_groupnorm_silu(None, 1, None, 1, None, None, 1, 1, 32, 16, 32, 1e-5, 1, None) == -1
+    assert lib.pgn_cfg_ddim_step(None, None, 1, None, None, None, 0, 16, 7.0, 1, 1, 1, 1, 0, 0, 0.0, None) == -1
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) & ~15
+    # head_dim other than 64 -> unsupported, 3-channel groups that do not divide -> invalid
+    assert lib.pgn_attention_fwd(p16, p16, p16, p16, 1, 1, 1, 1, 1, 40, *([8] * 12), None, 0, 0.1, None) == -2
+    assert lib.pgn_groupnorm_silu(p16, 1, p16, 1, None, None, 1, 1, 30, 16, 32, 1e-5, 1, None) == -1

@@ -1,0 +1,281 @@
+"""GPU parity tests of the four HIP kernels, called through the C ABI (pigeon_amd.ops -> ctypes -> libpigeon_hip).
+
+Bar (SURVEY.md §8 / BASELINE.json north_star): bit-exact for the integer/byte work (gather) and for the step
+kernels in reference-rounding mode; stated tolerances for GroupNorm+SiLU and attention (fp32 math on bf16 data,
+one bf16 rounding of the result).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import ops_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pigeon_amd import ops as _ops
+    return _ops
+
+
+DEV = "cuda"
+
+
+def _codebook(seed=0, n=16384, d=32):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(n, d, generator=g)
+    return torch.nn.functional.normalize(w, p=2, dim=-1)  # modeling_visual_tokenzier.py:59-61
+
+
+def _token_cases():
+    g = torch.Generator().manual_seed(123)
+    def valid(n):
+        return torch.randint(32002, 32002 + 16384, (n,), generator=g)
+    cases = []
+    # what llama.generate returns: [valid ids] + eos(32001) + pad(2) up to the batch max (inference.py:268-282)
+    a = torch.cat([valid(90), torch.tensor([32001]), torch.full((40,), 2)])
+    b = torch.cat([torch.tensor([32000]), valid(255), torch.tensor([32001])])
+    c = torch.cat([valid(300)])                                  # > 256 valid ids -> truncated
+    d = torch.tensor([2, 2, 32000, 32001, 5, 31999])             # nothing survives the filter
+    e = torch.cat([valid(20), torch.tensor([2, 32001]), valid(7)])  # specials in the middle
+    f = valid(256)
+    cases.append([a, b, c, d, e, f])
+    cases.append([valid(1)])
+    cases.append([valid(n) for n in (64, 65, 63, 128, 1, 256, 257, 300, 299)] + [d])
+    return cases
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+def test_token_gather_bit_exact(ops, dtype):
+    cb = _codebook()
+    for toks in _token_cases():
+        want, want_nums = ops_ref.token_gather_ref(toks, cb, dtype)
+        got = ops.token_gather([t.to(DEV) for t in toks], cb.to(DEV), out_dtype=dtype, check=True)
+        nums = got["token_nums"].cpu()
+        assert torch.equal(nums, want_nums)
+        total = int(want_nums.sum())
+        assert torch.equal(got["packed"][:total].cpu().view(torch.uint8), want.view(torch.uint8))
+        pad, mask = ops_ref.pad_and_mask_ref(want, want_nums, pad_len=256)
+        assert torch.equal(got["padded"].cpu().view(torch.uint8), pad.view(torch.uint8))
+        assert torch.equal(got["mask"].cpu().view(torch.uint8), mask.view(torch.uint8))
+
+
+def test_token_gather_rectangular_batch_and_bad_id(ops):
+    cb = _codebook(1)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(32002, 32002 + 16384, (16, 301), generator=g)
+    ids[:, 200:] = 2
+    ids[3, 150] = 32001
+    want, nums = ops_ref.token_gather_ref(list(ids), cb)
+    got = ops.token_gather(ids.to(DEV), cb.to(DEV), check=True)
+    assert torch.equal(got["token_nums"].cpu(), nums)
+    assert torch.equal(got["packed"][: int(nums.sum())].cpu().view(torch.int16), want.view(torch.int16))
+    bad = ids.clone()
+    bad[0, 0] = 32002 + 16384  # F.embedding would raise IndexError
+    with pytest.raises(IndexError):
+        ops.token_gather(bad.to(DEV), cb.to(DEV), check=True)
+
+
+def _step_inputs(shape, edt, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    noise_pred = torch.randn((2 * shape[0],) + shape[1:], generator=g).to(edt)
+    sample = torch.randn(shape, generator=g) * 3.0
+    return noise_pred, sample
+
+
+@pytest.mark.parametrize("edt", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("pred", ["epsilon", "sample", "v_prediction"])
+def test_cfg_ddim_step_bit_exact(ops, edt, pred):
+    # [B,4,h,w] incl. the BASELINE config-2 size (16x4x128x128) and a size with a scalar tail
+    for shape, g in (((16, 4, 128, 128), 7.0), ((3, 4, 19, 13), 7.1), ((1, 4, 152, 104), 5.0)):
+        noise_pred, sample = _step_inputs(shape, edt)
+        a_t, a_p = torch.tensor(0.2174), torch.tensor(0.3021)
+        for clip, ucm in ((None, False), (1.0, False), (1.0, True)):
+            want_prev, want_x0 = ops_ref.ddim_step_ref(ops_ref.cfg_combine_ref(noise_pred, g), sample, a_t, a_p, pred,
+                                                        clip, ucm)
+            got_prev, got_x0 = ops.cfg_ddim_step(noise_pred.to(DEV), sample.to(DEV), g, float(a_t ** 0.5),
+                                                 float((1 - a_t) ** 0.5), float(a_p ** 0.5), float((1 - a_p) ** 0.5),
+                                                 prediction_type=pred, clip_sample_range=clip,
+                                                 use_clipped_model_output=ucm, return_pred_x0=True)
+            assert got_prev.dtype == want_prev.dtype == torch.float32
+            assert torch.equal(got_prev.cpu(), want_prev), (shape, clip, ucm)
+            assert torch.equal(got_x0.cpu(), want_x0.float()), (shape, clip, ucm)
+
+
+def test_cfg_ddim_step_fused_fp32_is_close_and_no_guidance_path(ops):
+    noise_pred, sample = _step_inputs((4, 4, 64, 64), torch.bfloat16)
+    a_t, a_p = torch.tensor(0.5), torch.tensor(0.7)
+    args = (7.0, float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_p ** 0.5), float((1 - a_p) ** 0.5))
+    exact, _ = ops.cfg_ddim_step(noise_pred.to(DEV), sample.to(DEV), *args)
+    fused, _ = ops.cfg_ddim_step(noise_pred.to(DEV), sample.to(DEV), *args, fused_fp32=True)
+    # fused mode skips three bf16 roundings of O(10) magnitude values: tolerance 2^-7 relative of |eps_cfg|
+    assert (exact - fused).abs().max().item() < 0.25
+    text = noise_pred[4:]
+    want, _ = ops_ref.ddim_step_ref(text, sample, a_t, a_p)
+    got, _ = ops.cfg_ddim_step(None, sample.to(DEV), *args, eps_text=text.to(DEV))
+    assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("pred", ["epsilon", "v_prediction", "sample"])
+def test_cfg_euler_step_bit_exact(ops, pred):
+    noise_pred, sample = _step_inputs((2, 4, 64, 64), torch.bfloat16, seed=3)
+    sigma, sigma_next = torch.tensor(7.3125), torch.tensor(5.0411)
+    want, want_x0 = ops_ref.euler_step_ref(ops_ref.cfg_combine_ref(noise_pred, 7.0), sample, sigma, sigma_next, pred)
+    got, got_x0 = ops.cfg_euler_step(noise_pred.to(DEV), sample.to(DEV), 7.0, float(sigma), float(sigma_next), pred,
+                                     return_pred_x0=True)
+    assert got.dtype == torch.bfloat16  # diffusers casts prev_sample back to model_output.dtype
+    assert torch.equal(got.cpu(), want)
+    # second step: bf16 latents in
+    want2, _ = ops_ref.euler_step_ref(ops_ref.cfg_combine_ref(noise_pred, 7.0), want, sigma_next, torch.tensor(3.3), pred)
+    got2, _ = ops.cfg_euler_step(noise_pred.to(DEV), got, 7.0, float(sigma_next), 3.3, pred)
+    assert torch.equal(got2.cpu(), want2)
+    # fp32-latent variant keeps full precision
+    got32, _ = ops.cfg_euler_step(noise_pred.to(DEV), sample.to(DEV), 7.0, float(sigma), float(sigma_next), pred,
+                                  out_dtype=torch.float32)
+    want32 = ops_ref.euler_step_ref(ops_ref.cfg_combine_ref(noise_pred, 7.0).float(), sample, sigma, sigma_next, pred)[0]
+    assert got32.dtype == torch.float32
+    assert (got32.cpu() - want32).abs().max() < 0.3  # bf16 rounding of sigma*eps, |.| up to ~40
+
+
+def test_cfg_expand_scale(ops):
+    x = torch.randn(4, 4, 32, 32)
+    for div in (1.0, float((torch.tensor(7.3) ** 2 + 1) ** 0.5)):
+        got = ops.cfg_expand_scale(x.to(DEV), torch.bfloat16, div)
+        want = torch.cat([x / div] * 2).to(torch.bfloat16)
+        assert torch.equal(got.cpu(), want)
+
+
+# (N, C, H, W, groups, eps, silu, dtype, affine)
+GN_CASES = [
+    (2, 320, 128, 128, 32, 1e-5, True, torch.bfloat16, True),    # streaming path, 10 ch x 16384
+    (2, 640, 64, 64, 32, 1e-5, True, torch.bfloat16, True),      # resident R=16
+    (2, 1280, 32, 32, 32, 1e-5, True, torch.bfloat16, True),     # resident R=8
+    (2, 2560, 32, 32, 32, 1e-5, True, torch.bfloat16, True),     # resident R=16 (80 ch x 1024)
+    (1, 960, 128, 128, 32, 1e-5, True, torch.bfloat16, True),    # streaming, 30 ch x 16384
+    (2, 640, 64, 64, 32, 1e-6, False, torch.bfloat16, True),     # Transformer2DModel.norm (no SiLU)
+    (2, 640, 76, 52, 32, 1e-5, True, torch.bfloat16, True),      # ragged 1216x832 level 1 (HW = 3952)
+    (2, 1280, 38, 26, 32, 1e-5, True, torch.bfloat16, True),     # HW = 988, vectors straddle channels
+    (2, 1920, 38, 26, 32, 1e-5, True, torch.bfloat16, True),
+    (3, 64, 16, 16, 32, 1e-5, True, torch.float32, True),        # fp32 config
+    (2, 128, 8, 8, 32, 1e-5, True, torch.float16, True),
+    (2, 64, 5, 3, 32, 1e-5, True, torch.bfloat16, False),        # scalar path, no affine
+    (1, 32, 1, 1, 32, 1e-5, False, torch.float32, True),         # one element per group
+]
+
+
+@pytest.mark.parametrize("case", GN_CASES, ids=[f"{c[1]}x{c[2]}x{c[3]}-{str(c[7]).split('.')[-1]}" for c in GN_CASES])
+def test_groupnorm_silu_matches_oracle(ops, case):
+    N, C, H, W, G, eps, silu, dtype, affine = case
+    g = torch.Generator().manual_seed(C + H)
+    # per-channel offsets and scales so mean != 0 and groups differ
+    x = (torch.randn(N, C, H, W, generator=g) * (0.5 + torch.rand(1, C, 1, 1, generator=g) * 2)
+         + torch.randn(1, C, 1, 1, generator=g)).to(dtype)
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype) if affine else None
+    b = (0.2 * torch.randn(C, generator=g)).to(dtype) if affine else None
+    want = ops_ref.group_norm_silu_ref(x, G, w, b, eps, silu)
+    got = ops.group_norm_silu(x.to(DEV), G, None if w is None else w.to(DEV), None if b is None else b.to(DEV), eps,
+                              silu).cpu()
+    assert got.dtype == dtype and got.shape == x.shape
+    err = (got.float() - want.float()).abs()
+    # tolerance: fp32 arithmetic both sides, one rounding to the io dtype -> at most 1 ulp of the io dtype
+    # (fp32 io: 1e-5 relative + 1e-5 absolute covers v_exp_f32 / v_rcp_f32 and summation-order differences)
+    ulp = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10, torch.float32: 1e-5}[dtype]
+    bound = ulp * want.float().abs() + (1e-5 if dtype == torch.float32 else 4 * ulp * 2.0 ** -7)
+    assert bool((err <= bound + 1e-6).all()), f"max err {err.max().item()} at {want.flatten()[err.argmax()].item()}"
+    if dtype != torch.float32:
+        assert (got != want).float().mean().item() < 0.02  # only rare 1-ulp rounding flips
+
+
+def test_groupnorm_full_size_statistics_property(ops):
+    # BASELINE config-2 size (B' = 32): too big for the CPU oracle in seconds -> size-independent property:
+    # without affine/activation every (sample, group) of the output has mean 0 and variance 1.
+    N, C, HW, G = 32, 320, 16384, 32
+    x = (torch.randn(N, C, HW, device=DEV) * 1.7 + 0.3).to(torch.bfloat16)
+    y = ops.group_norm_silu(x, G, None, None, 1e-5, silu=False, out_dtype=torch.float32)
+    yg = y.view(N, G, -1)
+    assert yg.mean(-1).abs().max().item() < 2e-3
+    assert (yg.var(-1, unbiased=False) - 1).abs().max().item() < 2e-3
+
+
+# (B, heads, Nq, Nk, dtype, bias)
+ATTN_CASES = [
+    (2, 10, 1024, 1024, torch.bfloat16, False),   # SDXL level-2 self-attention shape (heads reduced)
+    (1, 10, 4096, 4096, torch.bfloat16, False),   # SDXL level-1 self-attention
+    (2, 20, 1024, 256, torch.bfloat16, False),    # cross-attention to the 256 decoder tokens
+    (2, 5, 988, 988, torch.bfloat16, False),      # ragged: 1216x832 level 2
+    (1, 2, 3952, 3952, torch.bfloat16, False),    # ragged: 1216x832 level 1
+    (2, 4, 300, 77, torch.bfloat16, True),        # key padding bias, Nk tail
+    (3, 2, 1, 1, torch.bfloat16, False),
+    (2, 3, 257, 65, torch.float16, False),
+    (2, 8, 1024, 256, torch.bfloat16, True),      # lowres-style encoder_attention_mask
+]
+
+
+def _attn_inputs(B, H, Nq, Nk, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    C = H * 64
+    q = (torch.randn(B, Nq, C, generator=g) * 1.5).to(dtype)
+    k = (torch.randn(B, Nk, C, generator=g) * 1.5).to(dtype)
+    v = torch.randn(B, Nk, C, generator=g).to(dtype)
+    return q, k, v
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[f"B{c[0]}H{c[1]}q{c[2]}k{c[3]}{'b' if c[5] else ''}" for c in ATTN_CASES])
+def test_attention_matches_oracle(ops, case):
+    B, H, Nq, Nk, dtype, has_bias = case
+    q, k, v = _attn_inputs(B, H, Nq, Nk, dtype, Nq + Nk)
+    bias = None
+    if has_bias:
+        keep = torch.randint(1, Nk + 1, (B,), generator=torch.Generator().manual_seed(1))
+        mask = (torch.arange(Nk)[None, :] < keep[:, None]).float()
+        bias = (1.0 - mask) * -10000.0  # modeling_decoder.py:100-101 / diffusers encoder_attention_mask
+    want = ops_ref.attention_ref(q, k, v, H, None, bias).float()
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H, None, None if bias is None else bias.to(DEV)).cpu().float()
+    err = (got - want).abs().max().item()
+    # tolerance: P is rounded to bf16 before P.V (as in xformers' kernel) and the output once more:
+    # 2^-8 relative on O(1) values
+    tol = 2.0 ** -7 * max(1.0, want.abs().max().item())
+    assert err < tol, f"max abs err {err} (tol {tol})"
+
+
+def test_attention_strided_inputs_and_rescale_branch(ops):
+    # q/k/v as slices of one fused qkv projection output (non-contiguous rows), plus a late score spike that
+    # forces the online-softmax rescale in a non-first K tile (cdna guide rule 26)
+    B, H, N = 2, 3, 640
+    C = H * 64
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(torch.bfloat16)
+    qkv[:, 500, C:2 * C] = qkv[:, 17, 0:C] * 4.0   # key 500 aligned with query 17 -> max jumps in tile 7
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    want = ops_ref.attention_ref(q, k, v, H).float()
+    dq = qkv.to(DEV)
+    got = ops.attention(dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:], H).cpu().float()
+    assert (got - want).abs().max().item() < 2.0 ** -7 * max(1.0, want.abs().max().item())
+
+
+def test_attention_full_size_properties(ops):
+    # BASELINE config-2 level-1 self-attention (B' = 32, 10 heads, N = 4096): checked through properties.
+    B, H, N = 32, 10, 4096
+    C = H * 64
+    g = torch.Generator(device=DEV).manual_seed(0)
+    q = torch.randn(B, N, C, device=DEV, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, N, C, device=DEV, generator=g).to(torch.bfloat16)
+    ones = torch.ones(B, N, C, device=DEV, dtype=torch.bfloat16)
+    # rows of softmax sum to 1: V = 1 -> O = 1 (bf16 rounding of P only)
+    o = ops.attention(q, k, ones, H).float()
+    assert (o - 1).abs().max().item() < 2.0 ** -7
+    # linearity in V
+    v1 = torch.randn(B, N, C, device=DEV, generator=g).to(torch.bfloat16)
+    v2 = torch.randn(B, N, C, device=DEV, generator=g).to(torch.bfloat16)
+    o12 = ops.attention(q, k, (v1.float() + v2.float()).to(torch.bfloat16), H).float()
+    o1, o2 = ops.attention(q, k, v1, H).float(), ops.attention(q, k, v2, H).float()
+    assert (o12 - (o1 + o2)).abs().max().item() < 0.02
+    # one sampled (batch, head) against the oracle
+    b, h = 17, 6
+    sl = slice(h * 64, (h + 1) * 64)
+    want = ops_ref.attention_ref(q[b:b + 1, :, sl].cpu(), k[b:b + 1, :, sl].cpu(), v1[b:b + 1, :, sl].cpu(), 1).float()
+    assert (o1[b:b + 1, :, sl].cpu() - want).abs().max().item() < 2.0 ** -7
