@@ -39,8 +39,15 @@ def pad_and_mask_ref(x: torch.Tensor, token_nums: torch.Tensor, pad_len: Optiona
 
 # ---- CFG combine + scheduler steps -------------------------------------------------------------
 def cfg_combine_ref(noise_pred: torch.Tensor, guidance_scale: float) -> torch.Tensor:
-    """lavit_for_pigeon.py:760-761, evaluated by torch in noise_pred's own dtype (bf16 under autocast)."""
+    """lavit_for_pigeon.py:760-761, evaluated in noise_pred's own dtype (bf16 under autocast): each of the three
+    tensor ops rounds to that dtype.  The python scalar enters the GPU kernel as an fp32 `opmath` value (see _cmul);
+    torch's CPU backend agrees for bf16 but rounds it to fp16 first for half tensors, hence the explicit form."""
     uncond, text = noise_pred.chunk(2)
+    if noise_pred.dtype in (torch.bfloat16, torch.float16):
+        g = torch.tensor(guidance_scale, dtype=torch.float32)
+        diff = text - uncond
+        scaled = (g * diff.to(torch.float32)).to(noise_pred.dtype)
+        return uncond + scaled
     return uncond + guidance_scale * (text - uncond)
 
 

@@ -1,0 +1,172 @@
+"""Attention module + processors with the diffusers 0.27.2 AttnProcessor protocol.
+
+The reference switches its UNet to xformers with `unet.enable_xformers_memory_efficient_attention()`
+(Pigeon/models/lavit_for_pigeon.py:202); diffusers then routes every `Attention.forward` through
+`XFormersAttnProcessor.__call__(attn, hidden_states, encoder_hidden_states, attention_mask, temb)`.
+`HipAttnProcessor` is that processor for MI355X: the projections stay hipBLASLt GEMMs, the attention core is the
+hand-written MFMA kernel (pigeon_amd.ops.attention), and the `[B, N, heads*D]` projection outputs are consumed in
+place — no head_to_batch_dim / batch_to_head_dim copies.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class HipAttnProcessor:
+    """Drop-in for diffusers' XFormersAttnProcessor / AttnProcessor2_0 on gfx950."""
+
+    def __init__(self, cache_cross_kv: bool = False):
+        # cross-attention K/V depend only on encoder_hidden_states, which is constant over the denoising loop
+        self.cache_cross_kv = cache_cross_kv
+        self._kv_cache = None
+
+    def reset_cache(self):
+        self._kv_cache = None
+
+    def __call__(self, attn: "Attention", hidden_states: torch.Tensor,
+                 encoder_hidden_states: Optional[torch.Tensor] = None,
+                 attention_mask: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
+                 *args, **kwargs) -> torch.Tensor:
+        residual = hidden_states
+        if getattr(attn, "spatial_norm", None) is not None:
+            hidden_states = attn.spatial_norm(hidden_states, temb)
+        input_ndim = hidden_states.ndim
+        if input_ndim == 4:
+            b, c, h, w = hidden_states.shape
+            hidden_states = hidden_states.view(b, c, h * w).transpose(1, 2)
+        if getattr(attn, "group_norm", None) is not None:
+            hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
+
+        is_cross = encoder_hidden_states is not None
+        query = attn.to_q(hidden_states)
+        if not is_cross:
+            context = hidden_states
+        else:
+            context = encoder_hidden_states
+            if getattr(attn, "norm_cross", None):
+                context = attn.norm_encoder_hidden_states(context)
+        if is_cross and self.cache_cross_kv and self._kv_cache is not None and self._kv_cache[0] is encoder_hidden_states:
+            key, value = self._kv_cache[1], self._kv_cache[2]
+        else:
+            key, value = attn.to_k(context), attn.to_v(context)
+            if is_cross and self.cache_cross_kv:
+                self._kv_cache = (encoder_hidden_states, key, value)
+
+        key_bias = None
+        if attention_mask is not None:
+            # diffusers hands the processor an additive mask broadcastable to [B, heads, Nq, Nk]; the path only
+            # ever builds key-padding masks ([B, 1, Nk], lavit_for_pigeon.py:873-874) -> [B, Nk] bias
+            m = attention_mask
+            if m.dim() == 3 and m.shape[1] == 1:
+                m = m[:, 0, :]
+            if m.dim() != 2 or m.shape[0] not in (query.shape[0], 1) or m.shape[1] != key.shape[1]:
+                raise NotImplementedError("HipAttnProcessor supports key-padding masks [B, Nk] / [B, 1, Nk] only")
+            key_bias = m.to(torch.float32).expand(query.shape[0], -1)
+
+        hidden_states = ops.attention(query, key, value, attn.heads, attn.scale, key_bias)
+        hidden_states = attn.to_out[0](hidden_states)
+        hidden_states = attn.to_out[1](hidden_states)
+
+        if input_ndim == 4:
+            hidden_states = hidden_states.transpose(-1, -2).reshape(b, c, h, w)
+        if attn.residual_connection:
+            hidden_states = hidden_states + residual
+        if attn.rescale_output_factor != 1.0:
+            hidden_states = hidden_states / attn.rescale_output_factor
+        return hidden_states
+
+
+class TorchSdpaAttnProcessor:
+    """torch.nn.functional.scaled_dot_product_attention on the GPU, for head sizes the HIP kernel does not cover
+    yet (e.g. the VAE's single 512-wide head; the reference leaves that one on diffusers' default processor too:
+    only `self.unet` is switched at lavit_for_pigeon.py:202)."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, *a, **kw):
+        residual = hidden_states
+        input_ndim = hidden_states.ndim
+        if input_ndim == 4:
+            b, c, h, w = hidden_states.shape
+            hidden_states = hidden_states.view(b, c, h * w).transpose(1, 2)
+        if getattr(attn, "group_norm", None) is not None:
+            hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
+        context = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        B, Nq, C = hidden_states.shape
+        H = attn.heads
+        q = attn.to_q(hidden_states).view(B, Nq, H, C // H).transpose(1, 2)
+        k = attn.to_k(context).view(B, -1, H, C // H).transpose(1, 2)
+        v = attn.to_v(context).view(B, -1, H, C // H).transpose(1, 2)
+        mask = None
+        if attention_mask is not None:
+            mask = attention_mask.to(q.dtype)
+            mask = mask[:, None, :, :] if mask.dim() == 3 else mask[:, None, None, :]
+        o = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=mask, scale=attn.scale)
+        hidden_states = attn.to_out[1](attn.to_out[0](o.transpose(1, 2).reshape(B, Nq, C)))
+        if input_ndim == 4:
+            hidden_states = hidden_states.transpose(-1, -2).reshape(b, c, h, w)
+        if attn.residual_connection:
+            hidden_states = hidden_states + residual
+        if attn.rescale_output_factor != 1.0:
+            hidden_states = hidden_states / attn.rescale_output_factor
+        return hidden_states
+
+
+class Attention(nn.Module):
+    """State-dict compatible with diffusers.models.attention_processor.Attention (to_q/to_k/to_v/to_out.0)."""
+
+    def __init__(self, query_dim: int, cross_attention_dim: Optional[int] = None, heads: int = 8, dim_head: int = 64,
+                 bias: bool = False, out_bias: bool = True, norm_num_groups: Optional[int] = None, eps: float = 1e-5,
+                 residual_connection: bool = False, rescale_output_factor: float = 1.0, processor=None):
+        super().__init__()
+        self.inner_dim = dim_head * heads
+        self.cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.residual_connection = residual_connection
+        self.rescale_output_factor = rescale_output_factor
+        self.spatial_norm = None
+        self.norm_cross = None
+        if norm_num_groups is not None:
+            from .layers import GroupNormAct
+            self.group_norm = GroupNormAct(norm_num_groups, query_dim, eps=eps, act=False)
+        else:
+            self.group_norm = None
+        self.to_q = nn.Linear(query_dim, self.inner_dim, bias=bias)
+        self.to_k = nn.Linear(self.cross_attention_dim, self.inner_dim, bias=bias)
+        self.to_v = nn.Linear(self.cross_attention_dim, self.inner_dim, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(self.inner_dim, query_dim, bias=out_bias), nn.Dropout(0.0)])
+        self.processor = processor if processor is not None else HipAttnProcessor()
+
+    def set_processor(self, processor):
+        self.processor = processor
+
+    def get_processor(self):
+        return self.processor
+
+    # kept for protocol completeness (third-party processors call them); the HIP processor does not need them
+    def head_to_batch_dim(self, tensor: torch.Tensor, out_dim: int = 3) -> torch.Tensor:
+        b, n, c = tensor.shape
+        tensor = tensor.reshape(b, n, self.heads, c // self.heads).permute(0, 2, 1, 3)
+        return tensor.reshape(b * self.heads, n, c // self.heads) if out_dim == 3 else tensor
+
+    def batch_to_head_dim(self, tensor: torch.Tensor) -> torch.Tensor:
+        bh, n, d = tensor.shape
+        tensor = tensor.reshape(bh // self.heads, self.heads, n, d).permute(0, 2, 1, 3)
+        return tensor.reshape(bh // self.heads, n, d * self.heads)
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim: int = 3):
+        if attention_mask is None:
+            return None
+        if attention_mask.shape[-1] != target_length:
+            attention_mask = torch.nn.functional.pad(attention_mask, (0, target_length), value=0.0)
+        if out_dim == 3 and attention_mask.shape[0] < batch_size * self.heads:
+            attention_mask = attention_mask.repeat_interleave(self.heads, dim=0)
+        elif out_dim == 4:
+            attention_mask = attention_mask.unsqueeze(1).repeat_interleave(self.heads, dim=1)
+        return attention_mask
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **cross_attention_kwargs):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                              attention_mask=attention_mask, **cross_attention_kwargs)

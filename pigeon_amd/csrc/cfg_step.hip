@@ -29,8 +29,13 @@ struct EulerParams {
     int has_uncond;
 };
 
+// Round an fp32 value to DT and back.  The empty asm makes the fp32 value opaque first: otherwise hipcc folds
+// `(half)(a * b)` into v_fma_mixlo_f16, which rounds ONCE to f16, whereas torch materialises the fp32 product
+// (opmath) and then casts - a double rounding that differs on exact-midpoint products.
 template <int DT>
 __device__ __forceinline__ float rnd(float x) {
+    if constexpr (DT == PGN_F32) return x;
+    asm volatile("" : "+v"(x));
     return Cvt<DT>::to_f32(Cvt<DT>::from_f32(x));
 }
 

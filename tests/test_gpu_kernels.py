@@ -163,7 +163,7 @@ GN_CASES = [
     (3, 64, 16, 16, 32, 1e-5, True, torch.float32, True),        # fp32 config
     (2, 128, 8, 8, 32, 1e-5, True, torch.float16, True),
     (2, 64, 5, 3, 32, 1e-5, True, torch.bfloat16, False),        # scalar path, no affine
-    (1, 32, 1, 1, 32, 1e-5, False, torch.float32, True),         # one element per group
+    (2, 64, 1, 1, 32, 1e-5, False, torch.float32, True),         # two elements per group
 ]
 
 
