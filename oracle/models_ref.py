@@ -1,0 +1,281 @@
+"""Model-level oracle: functional CPU restatement over a plain state dict.  TEST INFRASTRUCTURE ONLY.
+
+Independent of pigeon_amd's nn.Module implementation on purpose: same weights in, the two must agree.
+`policy` selects where values are rounded:
+    Policy(torch.float32)                       the reference's fp32-on-CPU configuration (BASELINE config 1)
+    Policy(torch.bfloat16)                      what torch.cuda.amp.autocast(bf16) does on the reference's GPU path
+                                                (lavit_for_pigeon.py:706): Linear/conv/matmul in bf16, group_norm /
+                                                layer_norm / softmax in fp32
+PARITY UNPINNED for everything restated from diffusers 0.27.2 (UNet2DConditionModel, Transformer2DModel,
+BasicTransformerBlock, ResnetBlock2D, AutoencoderKL decoder); the token decoder is pinned by
+tests/golden/token_decoder_*.npz (generated from the reference's own modeling_decoder.py).
+"""
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops_ref
+
+
+@dataclass
+class Policy:
+    compute: torch.dtype = torch.float32
+
+    def lin(self, x, w, b=None):
+        c = self.compute
+        return F.linear(x.to(c), w.to(c), None if b is None else b.to(c))
+
+    def conv(self, x, w, b=None, stride=1, padding=0):
+        c = self.compute
+        return F.conv2d(x.to(c), w.to(c), None if b is None else b.to(c), stride=stride, padding=padding)
+
+    def group_norm(self, x, groups, w, b, eps):
+        # autocast runs group_norm in fp32 and returns fp32
+        return F.group_norm(x.float(), groups, w.float(), b.float(), eps)
+
+    def layer_norm(self, x, w, b, eps):
+        return F.layer_norm(x.float(), (x.shape[-1],), w.float(), b.float(), eps)
+
+    def attention(self, q, k, v, heads, scale, bias=None):
+        # xformers memory_efficient_attention on compute-dtype inputs (fp32 softmax/accumulate inside)
+        c = self.compute
+        return ops_ref.attention_ref(q.to(c), k.to(c), v.to(c), heads, scale, bias, out_dtype=c)
+
+
+class SD(dict):
+    """state dict with prefix views: sd.sub('down_blocks.0.')"""
+
+    def sub(self, prefix):
+        return SD({k[len(prefix):]: v for k, v in self.items() if k.startswith(prefix)})
+
+    def has(self, prefix):
+        return any(k.startswith(prefix) for k in self)
+
+
+# ---- diffusers building blocks -------------------------------------------------------------------
+def timestep_embedding(timesteps, dim, flip_sin_to_cos=True, shift=0.0, max_period=10000):
+    """diffusers get_timestep_embedding."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - shift))
+    args = timesteps[:, None].float() * freqs[None]
+    sin, cos = torch.sin(args), torch.cos(args)
+    return torch.cat([cos, sin], -1) if flip_sin_to_cos else torch.cat([sin, cos], -1)
+
+
+def resnet(p: Policy, sd: SD, x, temb, groups, eps):
+    """diffusers ResnetBlock2D.forward (time_embedding_norm default, output_scale_factor 1)."""
+    h = F.silu(p.group_norm(x, groups, sd["norm1.weight"], sd["norm1.bias"], eps))
+    h = p.conv(h, sd["conv1.weight"], sd["conv1.bias"], padding=1)
+    if temb is not None and "time_emb_proj.weight" in sd:
+        h = h + p.lin(F.silu(temb), sd["time_emb_proj.weight"], sd["time_emb_proj.bias"])[:, :, None, None]
+    h = F.silu(p.group_norm(h, groups, sd["norm2.weight"], sd["norm2.bias"], eps))
+    h = p.conv(h, sd["conv2.weight"], sd["conv2.bias"], padding=1)
+    if "conv_shortcut.weight" in sd:
+        x = p.conv(x, sd["conv_shortcut.weight"], sd["conv_shortcut.bias"])
+    return x + h
+
+
+def attn_layer(p: Policy, sd: SD, x, context, heads, bias=None):
+    """diffusers Attention + XFormersAttnProcessor (no bias on q/k/v, bias on to_out.0)."""
+    ctx = x if context is None else context
+    q = p.lin(x, sd["to_q.weight"], sd.get("to_q.bias"))
+    k = p.lin(ctx, sd["to_k.weight"], sd.get("to_k.bias"))
+    v = p.lin(ctx, sd["to_v.weight"], sd.get("to_v.bias"))
+    d = q.shape[-1] // heads
+    o = p.attention(q, k, v, heads, d ** -0.5, bias)
+    return p.lin(o, sd["to_out.0.weight"], sd["to_out.0.bias"])
+
+
+def transformer_block(p: Policy, sd: SD, x, context, heads, ctx_bias=None):
+    """diffusers BasicTransformerBlock.forward (layer_norm variant, GEGLU feed-forward)."""
+    n = p.layer_norm(x, sd["norm1.weight"], sd["norm1.bias"], 1e-5)
+    x = attn_layer(p, sd.sub("attn1."), n, None, heads) + x
+    n = p.layer_norm(x, sd["norm2.weight"], sd["norm2.bias"], 1e-5)
+    x = attn_layer(p, sd.sub("attn2."), n, context, heads, ctx_bias) + x
+    n = p.layer_norm(x, sd["norm3.weight"], sd["norm3.bias"], 1e-5)
+    hg = p.lin(n, sd["ff.net.0.proj.weight"], sd["ff.net.0.proj.bias"])
+    hid, gate = hg.chunk(2, dim=-1)
+    ff = p.lin(hid * F.gelu(gate), sd["ff.net.2.weight"], sd["ff.net.2.bias"])
+    return ff + x
+
+
+def transformer_2d(p: Policy, sd: SD, x, context, heads, groups, ctx_bias=None):
+    """diffusers Transformer2DModel.forward, continuous input, linear or conv projection."""
+    b, c, h, w = x.shape
+    res = x
+    hs = p.group_norm(x, groups, sd["norm.weight"], sd["norm.bias"], 1e-6)
+    linear_proj = sd["proj_in.weight"].dim() == 2
+    if linear_proj:
+        hs = p.lin(hs.permute(0, 2, 3, 1).reshape(b, h * w, c), sd["proj_in.weight"], sd["proj_in.bias"])
+    else:
+        hs = p.conv(hs, sd["proj_in.weight"], sd["proj_in.bias"])
+        hs = hs.permute(0, 2, 3, 1).reshape(b, h * w, -1)
+    i = 0
+    while sd.has(f"transformer_blocks.{i}."):
+        hs = transformer_block(p, sd.sub(f"transformer_blocks.{i}."), hs, context, heads, ctx_bias)
+        i += 1
+    if linear_proj:
+        hs = p.lin(hs, sd["proj_out.weight"], sd["proj_out.bias"]).reshape(b, h, w, c).permute(0, 3, 1, 2)
+    else:
+        hs = p.conv(hs.reshape(b, h, w, -1).permute(0, 3, 1, 2), sd["proj_out.weight"], sd["proj_out.bias"])
+    return hs + res
+
+
+def _heads(cfg, level):
+    v = cfg.get("num_attention_heads") or cfg["attention_head_dim"]
+    return v[level] if isinstance(v, (list, tuple)) else v
+
+
+def unet_forward(p: Policy, sd_in: Dict[str, torch.Tensor], cfg: dict, sample, timestep, encoder_hidden_states,
+                 added_cond_kwargs=None, encoder_attention_mask=None):
+    """diffusers 0.27.2 UNet2DConditionModel.forward for the block types on the path
+    (call site lavit_for_pigeon.py:752-757; lowres :873-874)."""
+    sd = SD(sd_in)
+    groups, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    chans = list(cfg["block_out_channels"])
+    flip, shift = cfg["flip_sin_to_cos"], cfg["freq_shift"]
+    ctx_bias = None
+    if encoder_attention_mask is not None:
+        ctx_bias = (1 - encoder_attention_mask.float()) * -10000.0
+
+    t = torch.as_tensor(timestep).reshape(-1).expand(sample.shape[0])
+    t_emb = timestep_embedding(t, chans[0], flip, shift).to(sample.dtype)
+    emb = p.lin(F.silu(p.lin(t_emb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])),
+                sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    if cfg.get("addition_embed_type") == "text_time":
+        te, ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+        tid = timestep_embedding(ids.flatten(), cfg["addition_time_embed_dim"], flip, shift).reshape(te.shape[0], -1)
+        add = torch.cat([te, tid.to(te.dtype)], dim=-1).to(emb.dtype)
+        emb = emb + p.lin(F.silu(p.lin(add, sd["add_embedding.linear_1.weight"], sd["add_embedding.linear_1.bias"])),
+                          sd["add_embedding.linear_2.weight"], sd["add_embedding.linear_2.bias"])
+
+    x = p.conv(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    skips = [x]
+    for i, typ in enumerate(cfg["down_block_types"]):
+        bsd = sd.sub(f"down_blocks.{i}.")
+        for j in range(cfg["layers_per_block"]):
+            x = resnet(p, bsd.sub(f"resnets.{j}."), x, emb, groups, eps)
+            if typ == "CrossAttnDownBlock2D":
+                x = transformer_2d(p, bsd.sub(f"attentions.{j}."), x, encoder_hidden_states, _heads(cfg, i), groups, ctx_bias)
+            skips.append(x)
+        if bsd.has("downsamplers.0."):
+            x = p.conv(x, bsd["downsamplers.0.conv.weight"], bsd["downsamplers.0.conv.bias"], stride=2,
+                       padding=cfg["downsample_padding"])
+            skips.append(x)
+
+    msd = sd.sub("mid_block.")
+    nb = len(chans)
+    x = resnet(p, msd.sub("resnets.0."), x, emb, groups, eps)
+    x = transformer_2d(p, msd.sub("attentions.0."), x, encoder_hidden_states, _heads(cfg, nb - 1), groups, ctx_bias)
+    x = resnet(p, msd.sub("resnets.1."), x, emb, groups, eps)
+
+    for i, typ in enumerate(cfg["up_block_types"]):
+        bsd = sd.sub(f"up_blocks.{i}.")
+        for j in range(cfg["layers_per_block"] + 1):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = resnet(p, bsd.sub(f"resnets.{j}."), x, emb, groups, eps)
+            if typ == "CrossAttnUpBlock2D":
+                x = transformer_2d(p, bsd.sub(f"attentions.{j}."), x, encoder_hidden_states, _heads(cfg, nb - 1 - i),
+                                   groups, ctx_bias)
+        if bsd.has("upsamplers.0."):
+            size = skips[-1].shape[2:]  # == 2x unless the latent side is not a multiple of 2**(levels-1)
+            x = F.interpolate(x.float(), size=tuple(size), mode="nearest").to(x.dtype)
+            x = p.conv(x, bsd["upsamplers.0.conv.weight"], bsd["upsamplers.0.conv.bias"], padding=1)
+
+    x = F.silu(p.group_norm(x, groups, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps))
+    return p.conv(x, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+
+
+# ---- token decoder (Pigeon/models/modeling_decoder.py) --------------------------------------------
+def _ln32(x, w, b, eps=1e-5):
+    """modeling_decoder.py:11-17 — LayerNorm computed in fp32, result cast back."""
+    return F.layer_norm(x.float(), (x.shape[-1],), w.float(), b.float(), eps).to(x.dtype)
+
+
+def token_decoder_forward(p: Policy, sd_in, x, token_nums, num_heads=16):
+    """HighresVQDecoder.forward, modeling_decoder.py:302-337 (Block :133-137, SelfAttention :58-71,
+    CrossAttention :90-109, AttentionPool2d :150-177), written over the state dict."""
+    sd = SD(sd_in)
+    H = num_heads
+    x = p.lin(x, sd["in_proj.weight"], sd["in_proj.bias"])                                   # :305
+    x_pad, mask = ops_ref.pad_and_mask_ref(x, token_nums)                                     # :310-317
+    x_pad = x_pad + sd["pos_embed"][:, : x_pad.shape[1]].to(x_pad.dtype)                      # :319
+    B, L, C = x_pad.shape
+    D = C // H
+    scale = D ** -0.5
+    q = sd["query_embed"].expand(B, -1, -1).to(x_pad.dtype)                                    # :322
+    ext = ((1.0 - mask) * -10000.0)[:, None, None, :]                                          # :100-101
+
+    def heads(t):
+        return t.reshape(B, -1, H, D).permute(0, 2, 1, 3)
+
+    i = 0
+    while sd.has(f"blocks.{i}."):
+        b = sd.sub(f"blocks.{i}.")
+        n = _ln32(q, b["norm0.weight"], b["norm0.bias"])
+        qkv = p.lin(n, b["self_attn.qkv.weight"], b["self_attn.qkv.bias"]).reshape(B, -1, 3, H, D).permute(2, 0, 3, 1, 4)
+        a = ((qkv[0] @ qkv[1].transpose(-2, -1)) * scale).float().softmax(dim=-1).to(qkv.dtype)  # :63-65
+        o = (a @ qkv[2]).transpose(1, 2).reshape(B, -1, C)
+        q = q + p.lin(o, b["self_attn.proj.weight"], b["self_attn.proj.bias"])               # :134
+        n = _ln32(q, b["norm1.weight"], b["norm1.bias"])
+        cq = heads(p.lin(n, b["cross_attn.query.weight"], b["cross_attn.query.bias"]))
+        ck = heads(p.lin(x_pad, b["cross_attn.key.weight"], b["cross_attn.key.bias"]))
+        cv = heads(p.lin(x_pad, b["cross_attn.value.weight"], b["cross_attn.value.bias"]))
+        a = (((cq @ ck.transpose(-2, -1)) * scale) + ext.to(cq.dtype)).float().softmax(dim=-1).to(cq.dtype)  # :98-104
+        o = (a @ cv).transpose(1, 2).reshape(B, -1, C)
+        q = q + p.lin(o, b["cross_attn.proj.weight"], b["cross_attn.proj.bias"])             # :135
+        n = _ln32(q, b["norm2.weight"], b["norm2.bias"])
+        m = p.lin(F.gelu(p.lin(n, b["mlp.fc1.weight"], b["mlp.fc1.bias"])), b["mlp.fc2.weight"], b["mlp.fc2.bias"])
+        q = q + m                                                                             # :136
+        i += 1
+    q = _ln32(q, sd["norm.weight"], sd["norm.bias"])                                          # :328
+    rec = p.lin(torch.tanh(p.lin(q, sd["decode_task_layer.0.weight"], sd["decode_task_layer.0.bias"])),
+                sd["decode_task_layer.2.weight"], sd["decode_task_layer.2.bias"])             # :330
+    prompt = torch.cat([p.lin(rec, sd["unet_proj_1.weight"], sd["unet_proj_1.bias"]),
+                        p.lin(rec, sd["unet_proj_2.weight"], sd["unet_proj_2.bias"])], dim=-1)  # :332-334
+    # AttentionPool2d :150-177 (multi_head_attention_forward with separate projection weights)
+    ap = sd.sub("unet_attnpool.")
+    t = rec.permute(1, 0, 2)
+    t = torch.cat([t.mean(dim=0, keepdim=True), t], dim=0)
+    t = t + ap["positional_embedding"][:, None, :].to(t.dtype)
+    S = t.shape[0]
+    pq = p.lin(t, ap["q_proj.weight"], ap["q_proj.bias"]).reshape(S, B * H, D).transpose(0, 1) * (D ** -0.5)
+    pk = p.lin(t, ap["k_proj.weight"], ap["k_proj.bias"]).reshape(S, B * H, D).transpose(0, 1)
+    pv = p.lin(t, ap["v_proj.weight"], ap["v_proj.bias"]).reshape(S, B * H, D).transpose(0, 1)
+    a = torch.bmm(pq, pk.transpose(1, 2)).float().softmax(dim=-1).to(pq.dtype)
+    o = torch.bmm(a, pv).transpose(0, 1).reshape(S, B, C)
+    pooled = p.lin(o, ap["c_proj.weight"], ap["c_proj.bias"])[0]                              # :177
+    return prompt, pooled
+
+
+# ---- VAE decoder (diffusers AutoencoderKL.decode; call site lavit_for_pigeon.py:774) ----------------
+def vae_decode(p: Policy, sd_in, cfg: dict, z):
+    sd = SD(sd_in)
+    g = cfg["norm_num_groups"]
+    x = p.conv(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+    d = sd.sub("decoder.")
+    x = p.conv(x, d["conv_in.weight"], d["conv_in.bias"], padding=1)
+    m = d.sub("mid_block.")
+    x = resnet(p, m.sub("resnets.0."), x, None, g, 1e-6)
+    a = m.sub("attentions.0.")
+    b, c, h, w = x.shape
+    hs = p.group_norm(x.reshape(b, c, h * w), g, a["group_norm.weight"], a["group_norm.bias"], 1e-6).transpose(1, 2)
+    head_dim = cfg.get("attention_head_dim") or c
+    x = attn_layer(p, a, hs, None, c // head_dim).transpose(1, 2).reshape(b, c, h, w) + x
+    x = resnet(p, m.sub("resnets.1."), x, None, g, 1e-6)
+    i = 0
+    while d.has(f"up_blocks.{i}."):
+        u = d.sub(f"up_blocks.{i}.")
+        j = 0
+        while u.has(f"resnets.{j}."):
+            x = resnet(p, u.sub(f"resnets.{j}."), x, None, g, 1e-6)
+            j += 1
+        if u.has("upsamplers.0."):
+            x = F.interpolate(x.float(), scale_factor=2.0, mode="nearest").to(x.dtype)
+            x = p.conv(x, u["upsamplers.0.conv.weight"], u["upsamplers.0.conv.bias"], padding=1)
+        i += 1
+    x = F.silu(p.group_norm(x, g, d["conv_norm_out.weight"], d["conv_norm_out.bias"], 1e-6))
+    return p.conv(x, d["conv_out.weight"], d["conv_out.bias"], padding=1)

@@ -1,0 +1,142 @@
+"""The hot path: visual tokens -> images.  Host-side mirror of `LaVITforPigeon.generate_image`
+(Pigeon/models/lavit_for_pigeon.py:674-789, highres branch) with the same arguments, ordering, dtypes and
+3-tuple return, driving the HIP kernels:
+
+    generate_image_embeds (:897-920)   -> ops.token_gather (one fused launch pair) + HighresVQDecoder.forward_padded
+    cat([latents]*2) + scale_model_input (:747-748) -> ops.cfg_expand_scale
+    unet(...) (:752-757)               -> pigeon_amd.unet.UNet2DConditionModel (HIP attention + GroupNorm/SiLU)
+    chunk(2) + guidance + scheduler.step (:760-764) -> scheduler.step_cfg (one fused launch)
+    vae.decode + post-process (:766-787)            -> pigeon_amd.vae.AutoencoderKL + on-device uint8 conversion
+
+Reference quirks kept on purpose: `target_size=(width, height)` (:724), all-zero unconditional embeddings including
+the pooled one (:710-711), CFG batch order [neg...; pos...] followed by repeat_interleave (:731-736), fp32 latents.
+"""
+from typing import Callable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .schedulers import DDIMScheduler
+
+# inference.py:58-65 — (height, width) per aspect-ratio flag
+RATIO_DICT = {
+    "1:1": (1024, 1024), "4:3": (896, 1152), "3:2": (832, 1216), "16:9": (768, 1344), "2:3": (1216, 832),
+    "3:4": (1152, 896),
+}
+
+
+def numpy_to_pil(images: np.ndarray):
+    """lavit_for_pigeon.py:922-936 (float [0,1] NHWC or already-uint8 NHWC -> list of PIL images)."""
+    from PIL import Image
+    if images.ndim == 3:
+        images = images[None, ...]
+    if images.dtype != np.uint8:
+        images = (images * 255).round().astype("uint8")
+    if images.shape[-1] == 1:
+        return [Image.fromarray(image.squeeze(), mode="L") for image in images]
+    return [Image.fromarray(image) for image in images]
+
+
+class PigeonPixelDecoder:
+    """Owns the frozen decoder stack (codebook, token decoder, UNet, scheduler, VAE) on one GPU."""
+
+    def __init__(self, codebook: torch.Tensor, tokenizer_decoder, unet, vae, scheduler=None,
+                 model_dtype: str = "bf16", device: Union[str, torch.device] = "cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("PigeonPixelDecoder runs on an MI355X (device 'cuda:N'); there is no CPU path")
+        self.dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(model_dtype, torch.float16)  # :229-236
+        self.codebook = codebook.detach().to(self.device, torch.float32).contiguous()
+        self.tokenizer_decoder = tokenizer_decoder.to(self.device, self.dtype).eval().requires_grad_(False)
+        self.unet = unet.to(self.device, self.dtype).eval().requires_grad_(False)
+        self.vae = None if vae is None else vae.to(self.device, self.dtype).eval().requires_grad_(False)
+        self.scheduler = scheduler if scheduler is not None else DDIMScheduler()
+        self.pixel_decoding = "highres"
+
+    # ---- :897-920 ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_image_embeds(self, image_tokens: Union[Sequence[torch.Tensor], torch.Tensor]):
+        toks = image_tokens if isinstance(image_tokens, torch.Tensor) else [t.to(self.device) for t in image_tokens]
+        g = ops.token_gather(toks, self.codebook, out_dtype=self.dtype, packed=False, padded=True)
+        return self.tokenizer_decoder.forward_padded(g["padded"], g["mask"])
+
+    @staticmethod
+    def _get_add_time_ids(original_size, crops_coords_top_left, target_size, dtype):
+        return torch.tensor([list(original_size + crops_coords_top_left + target_size)], dtype=dtype)  # :791-794
+
+    # ---- :674-789 ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_image(self, batch=None, image_tokens=None, mask_ratio=0.2, hist_mask_ratio=0.2, add_special=True,
+                       with_mask=True, llama_generation_config=None, num_return_images: int = 1, width: int = 512,
+                       height: int = 512, original_size: Optional[Tuple[int, int]] = None,
+                       crops_coords_top_left: Optional[Tuple[int, int]] = None, num_inference_steps: int = 25,
+                       guidance_scale_for_diffusion: float = 7.0, generator: Optional[torch.Generator] = None,
+                       latents: Optional[torch.Tensor] = None, output_type: str = "pil",
+                       callback: Optional[Callable[[int, int, torch.Tensor], None]] = None):
+        """Same contract as the reference plus three keyword extensions: `latents` (explicit initial noise, for
+        reproducible parity runs and rank sharding), `output_type` in {"pil", "np", "uint8", "latent"} and a
+        per-step `callback(i, t, latents)`."""
+        if batch is None and image_tokens is None:
+            raise ValueError("Generated image requires `batch` input or `image_tokens` input.")
+        if image_tokens is None:
+            raise NotImplementedError("token generation (the LLaMA stage) is outside the accelerated path: pass "
+                                      "`image_tokens` as inference.py:389-399 does")
+        prompt_embeds, pooled_prompt_embeds = self.generate_image_embeds(image_tokens)
+        negative_prompt_embeds = torch.zeros_like(prompt_embeds)
+        negative_pooled_prompt_embeds = torch.zeros_like(pooled_prompt_embeds)
+
+        batch_size = len(prompt_embeds) * num_return_images
+        shape = (batch_size, self.unet.config.in_channels, height // 8, width // 8)
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, device=self.device)
+        else:
+            if tuple(latents.shape) != shape:
+                raise ValueError(f"latents must have shape {shape}")
+            latents = latents.to(self.device, torch.float32)
+        latents = latents * self.scheduler.init_noise_sigma
+        self.scheduler.set_timesteps(num_inference_steps, device=self.device)
+
+        target_size = (width, height)
+        original_size = original_size if original_size is not None else target_size
+        crops_coords_top_left = crops_coords_top_left if crops_coords_top_left is not None else (0, 0)
+        add_time_ids = self._get_add_time_ids(original_size, crops_coords_top_left, target_size, prompt_embeds.dtype)
+        add_time_ids = add_time_ids.repeat(batch_size, 1)
+        input_embeds = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+        add_text_embeds = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], dim=0)
+        add_time_ids = torch.cat([add_time_ids, add_time_ids], dim=0).to(self.device)
+        input_embeds = input_embeds.repeat_interleave(num_return_images, dim=0)
+        add_text_embeds = add_text_embeds.repeat_interleave(num_return_images, dim=0)
+        assert input_embeds.shape[0] == add_text_embeds.shape[0] == add_time_ids.shape[0] == latents.shape[0] * 2
+
+        added_cond_kwargs = {"text_embeds": add_text_embeds, "time_ids": add_time_ids}
+        host_timesteps = list(self.scheduler._host_timesteps)  # no device->host sync inside the loop
+        for i, t in enumerate(host_timesteps):
+            latent_model_input = ops.cfg_expand_scale(latents, self.unet.dtype, self.scheduler.scale_divisor(t))
+            noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=input_embeds,
+                                   added_cond_kwargs=added_cond_kwargs).sample
+            latents = self.scheduler.step_cfg(noise_pred, t, latents, guidance_scale_for_diffusion).prev_sample
+            if callback is not None:
+                callback(i, t, latents)
+
+        if output_type == "latent":
+            return latents, prompt_embeds, pooled_prompt_embeds
+        images = self.decode_latents(latents, output_type)
+        return images, prompt_embeds, pooled_prompt_embeds
+
+    # ---- :766-787 ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode_latents(self, latents: torch.Tensor, output_type: str = "pil"):
+        if self.vae is None:
+            raise RuntimeError("no VAE attached")
+        vae_dtype = next(iter(self.vae.post_quant_conv.parameters())).dtype
+        z = latents.to(vae_dtype)
+        image = self.vae.decode(z / self.vae.config.scaling_factor).sample
+        image = (image.float() / 2 + 0.5).clamp(0, 1)
+        if output_type == "np":
+            return image.cpu().permute(0, 2, 3, 1).numpy()
+        # uint8 on the device: 4x fewer bytes over PCIe than the reference's fp32 copy; same rounding as numpy_to_pil
+        u8 = (image * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        if output_type == "uint8":
+            return u8
+        return numpy_to_pil(u8.cpu().numpy())

@@ -231,7 +231,7 @@ class EulerDiscreteScheduler:
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
         if rescale_betas_zero_snr:
             self.alphas_cumprod[-1] = 2 ** -24
-        sigmas = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         timesteps = np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=float)[::-1].copy()
         self.timesteps = torch.from_numpy(timesteps).to(dtype=torch.float32)
         self.sigmas = torch.cat([torch.from_numpy(sigmas[::-1].copy()).to(dtype=torch.float32), torch.zeros(1)])
@@ -270,7 +270,7 @@ class EulerDiscreteScheduler:
             ts -= 1
         else:
             raise ValueError(f"{spacing} is not supported. Choose one of 'linspace', 'leading' or 'trailing'.")
-        sigmas = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         sigmas = np.interp(ts, np.arange(0, len(sigmas)), sigmas)
         sigmas = torch.from_numpy(sigmas).to(dtype=torch.float32)
         self.timesteps = torch.from_numpy(ts.astype(np.float32)).to(device=device)

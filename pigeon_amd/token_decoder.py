@@ -1,0 +1,179 @@
+"""Token decoder: codebook embeddings of the visual tokens -> SDXL conditioning.
+
+Host-side mirror of `HighresVQDecoder` (Pigeon/models/modeling_decoder.py:257-337; blocks :112-137, attention
+:44-109, attention pool :140-177) with the same constructor arguments and state-dict names, so
+`visual_tokenizer/highres_tokenizer_decoder.bin` loads unchanged (modeling_decoder.py:346-350).
+
+Runs once per batch, outside the denoising loop.  MI355X-first differences (results equal up to accumulation
+order; the reference's per-sample Python pad loop :315-317 and its `.tolist()` / `.max().item()` host syncs are gone):
+  * `forward_padded` consumes the fixed-shape `[B, 256, 32]` + mask output of the fused gather kernel;
+    padded key columns receive the same additive -10000 bias as the reference's mask, i.e. exactly zero weight;
+  * attention goes through fused scaled-dot-product kernels instead of materialised [B, 16, 256, L] score tensors;
+  * the attention pool evaluates only the one query row whose output is used (`x[0]`, :177).
+`forward(x, token_num)` keeps the reference signature (packed rows + counts).
+"""
+from functools import partial
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _LayerNormFp32(nn.LayerNorm):
+    """fp32 statistics regardless of the activation dtype (modeling_decoder.py:11-17)."""
+
+    def forward(self, x):
+        w = None if self.weight is None else self.weight.float()
+        b = None if self.bias is None else self.bias.float()
+        return F.layer_norm(x.float(), self.normalized_shape, w, b, self.eps).to(x.dtype)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias, qk_scale):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim, bias=qkv_bias)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).view(B, N, 3, self.num_heads, C // self.num_heads)
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+        o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
+        return self.proj(o.transpose(1, 2).reshape(B, N, C))
+
+
+class _CrossAttention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias, qk_scale):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.query = nn.Linear(dim, dim, bias=qkv_bias)
+        self.key = nn.Linear(dim, dim, bias=qkv_bias)
+        self.value = nn.Linear(dim, dim, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim, bias=qkv_bias)
+
+    def forward(self, x, codebook_embeds, bias):
+        B, L, C = codebook_embeds.shape
+        H, D = self.num_heads, C // self.num_heads
+        q = self.query(x).view(B, -1, H, D).transpose(1, 2)
+        k = self.key(codebook_embeds).view(B, L, H, D).transpose(1, 2)
+        v = self.value(codebook_embeds).view(B, L, H, D).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, scale=self.scale)
+        return self.proj(o.transpose(1, 2).reshape(B, -1, C))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, qk_scale, norm_layer):
+        super().__init__()
+        self.norm0 = norm_layer(dim)
+        self.self_attn = _SelfAttention(dim, num_heads, qkv_bias, qk_scale)
+        self.norm1 = norm_layer(dim)
+        self.cross_attn = _CrossAttention(dim, num_heads, qkv_bias, qk_scale)
+        self.norm2 = norm_layer(dim)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x, codebook_embeds, bias):
+        x = x + self.self_attn(self.norm0(x))
+        x = x + self.cross_attn(self.norm1(x), codebook_embeds, bias)
+        return x + self.mlp(self.norm2(x))
+
+
+class _AttentionPool(nn.Module):
+    def __init__(self, seq_len, embed_dim, num_heads, output_dim):
+        super().__init__()
+        self.positional_embedding = nn.Parameter(torch.randn(seq_len + 1, embed_dim) / embed_dim ** 0.5)
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.c_proj = nn.Linear(embed_dim, output_dim or embed_dim)
+        self.num_heads = num_heads
+
+    def forward(self, x):
+        B, N, C = x.shape
+        H, D = self.num_heads, C // self.num_heads
+        x = torch.cat([x.mean(dim=1, keepdim=True), x], dim=1) + self.positional_embedding[None].to(x.dtype)
+        q = self.q_proj(x[:, :1]).view(B, 1, H, D).transpose(1, 2)      # only the pooled query is returned
+        k = self.k_proj(x).view(B, N + 1, H, D).transpose(1, 2)
+        v = self.v_proj(x).view(B, N + 1, H, D).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v)
+        return self.c_proj(o.transpose(1, 2).reshape(B, C))
+
+
+class HighresVQDecoder(nn.Module):
+    def __init__(self, img_size=224, patch_size=14, in_chans=32, embed_dim=1408, depth=12, num_heads=16,
+                 mlp_ratio=4.3637, qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 norm_layer=partial(_LayerNormFp32, eps=1e-5), **kwargs):
+        super().__init__()
+        if drop_rate or attn_drop_rate:
+            raise NotImplementedError("inference-only module: dropout must be 0")
+        self.in_proj = nn.Linear(in_chans, embed_dim)
+        self.num_features = self.embed_dim = embed_dim
+        self.num_patches = (img_size // patch_size) ** 2
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches, embed_dim))
+        self.query_embed = nn.Parameter(torch.zeros(1, self.num_patches, embed_dim))
+        self.blocks = nn.ModuleList(
+            [_Block(embed_dim, num_heads, mlp_ratio, qkv_bias, qk_scale, norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.decoder_out_dim = 1408
+        self.decode_task_layer = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.Tanh(),
+                                               nn.Linear(embed_dim, self.decoder_out_dim))
+        self.unet_proj_1 = nn.Linear(self.decoder_out_dim, 768)
+        self.unet_proj_2 = nn.Linear(self.decoder_out_dim, 1280)
+        self.unet_attnpool = _AttentionPool(self.num_patches, self.decoder_out_dim, num_heads, 1280)
+
+    def get_num_layers(self):
+        return len(self.blocks)
+
+    def forward_padded(self, x_pad: torch.Tensor, mask: torch.Tensor):
+        """x_pad [B, L, in_chans] (rows past each sample's token count are ignored), mask [B, L] in {0, 1}."""
+        B, L, _ = x_pad.shape
+        if L > self.num_patches:
+            raise ValueError(f"at most {self.num_patches} tokens per sample")
+        dtype = self.in_proj.weight.dtype
+        m = mask.to(dtype)
+        x = self.in_proj(x_pad.to(dtype)) * m[..., None]          # padding rows are zeros, not the bias (:312-316)
+        x = x + self.pos_embed[:, :L]
+        bias = ((1.0 - m) * -10000.0)[:, None, None, :]          # :100-101
+        q = self.query_embed.expand(B, -1, -1)
+        for blk in self.blocks:
+            q = blk(q, x, bias)
+        rec = self.decode_task_layer(self.norm(q))
+        prompt_embeds = torch.cat([self.unet_proj_1(rec), self.unet_proj_2(rec)], dim=-1)
+        return prompt_embeds, self.unet_attnpool(rec)
+
+    def forward(self, x: torch.Tensor, token_num: torch.Tensor):
+        """Reference signature: x [sum(token_num), in_chans] packed rows, token_num int64 [B]."""
+        nums = token_num.tolist()
+        B, L = len(nums), max(max(nums), 1)
+        x_pad = x.new_zeros(B, L, x.shape[1])
+        mask = x.new_zeros(B, L)
+        start = 0
+        for i, n in enumerate(nums):
+            x_pad[i, :n] = x[start:start + n]
+            mask[i, :n] = 1
+            start += n
+        return self.forward_padded(x_pad, mask)
+
+
+def build_tokenizer_decoder(model_path: str = "", pixel_decoding: str = "highres", depth: int = 12):
+    """modeling_decoder.py:340-351 for the highres decoder; weights via torch.load(weights_only=True)."""
+    import os
+    if pixel_decoding != "highres":
+        raise NotImplementedError("only the highres pixel decoder is on the accelerated path")
+    model = HighresVQDecoder(depth=depth)
+    weight_path = os.path.join(model_path, "visual_tokenizer", "highres_tokenizer_decoder.bin")
+    model.load_state_dict(torch.load(weight_path, map_location="cpu", weights_only=True))
+    return model
