@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+import threading
+
 import torch
 import torch.distributed as dist
 
@@ -121,6 +123,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
+    t_start = time.perf_counter()
+    state = {"phase": "build"}
+
+    def heartbeat():   # keeps log watchers alive during long silent phases; stderr only
+        while state["phase"] != "done":
+            time.sleep(30)
+            if rank == 0 and state["phase"] != "done":
+                print(f"[bench {time.perf_counter() - t_start:6.0f}s] {state['phase']}", file=sys.stderr, flush=True)
+
+    threading.Thread(target=heartbeat, daemon=True).start()
+
     from pigeon_amd import ops, runner, synthetic
     pipe = synthetic.build_random_stack(device, "bf16", seed=123)
     if args.cross_kv_cache:
@@ -152,9 +165,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    state["phase"] = "warmup"
     for _ in range(args.warmup):
         one_step()
     fence()
+    state["phase"] = "timed steps"
     timer.enabled = not args.no_kernel_timing
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -188,6 +203,7 @@ def main():
                     "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
                     "launches": n, "avg_launch_us": secs / n * 1e6, "flop_per_launch": work / n}
 
+    state["phase"] = "cpu baseline"
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ips, t_embed, t_step = cpu_baseline(pipe, [t.cpu() for t in tokens], args.height, args.width,
@@ -213,6 +229,7 @@ def main():
             "attention_mfma_util_pct": None if roofline is None else 100.0 * roofline["frac"],
         }
         print(json.dumps(line), flush=True)
+    state["phase"] = "done"
     if world > 1:
         dist.destroy_process_group()
 

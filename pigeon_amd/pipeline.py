@@ -126,17 +126,26 @@ class PigeonPixelDecoder:
 
     # ---- :766-787 ------------------------------------------------------------------------------
     @torch.no_grad()
-    def decode_latents(self, latents: torch.Tensor, output_type: str = "pil"):
+    def decode_latents(self, latents: torch.Tensor, output_type: str = "pil", chunk: int = 1):
+        """VAE decode + post-process.  Images are decoded `chunk` at a time: samples are independent in the decoder,
+        and a 16 x 256 x 1024 x 1024 activation exceeds the 2^31-element limit of torch's nearest-upsample launch."""
         if self.vae is None:
             raise RuntimeError("no VAE attached")
         vae_dtype = next(iter(self.vae.post_quant_conv.parameters())).dtype
-        z = latents.to(vae_dtype)
-        image = self.vae.decode(z / self.vae.config.scaling_factor).sample
-        image = (image.float() / 2 + 0.5).clamp(0, 1)
+        z = latents.to(vae_dtype) / self.vae.config.scaling_factor
+        outs = []
+        for i in range(0, z.shape[0], max(1, chunk)):
+            image = self.vae.decode(z[i:i + chunk]).sample
+            image = (image.float() / 2 + 0.5).clamp(0, 1)
+            if output_type != "np":
+                # uint8 on the device: 4x fewer bytes over PCIe than the reference's fp32 copy; same rounding as
+                # numpy_to_pil ((x * 255).round(), half to even)
+                image = (image * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+            outs.append(image)
+        image = torch.cat(outs, dim=0)
         if output_type == "np":
             return image.cpu().permute(0, 2, 3, 1).numpy()
-        # uint8 on the device: 4x fewer bytes over PCIe than the reference's fp32 copy; same rounding as numpy_to_pil
-        u8 = (image * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        u8 = image
         if output_type == "uint8":
             return u8
         return numpy_to_pil(u8.cpu().numpy())
