@@ -15,15 +15,19 @@
 //     sub-tiles and read with ds_read_b64_tr_b16 (hardware transpose) as the A operand.
 //   * q/k/v/out are addressed through (batch, sequence, head) element strides: the [B, N, H*64] output
 //     of to_q/to_k/to_v is consumed in place, no head_to_batch_dim copy.
+#include <type_traits>
+
 #include "pgn_common.h"
 
 namespace {
 
 constexpr int ATT_D = 64;
-constexpr int ATT_BM = 256;      // query rows per workgroup
 constexpr int ATT_BN = 64;       // keys per tile
-constexpr int ATT_THREADS = 512;
 constexpr int ATT_TILE_ELEMS = ATT_BN * ATT_D;  // 4096 x 16-bit = 8 KiB
+// a workgroup = NWAVES wave64, 32 query rows each: NWAVES = 8 (256 rows, 2 waves per SIMD) for long key sequences,
+// NWAVES = 4 (128 rows, several workgroups per CU) when the key loop is short and prologue latency dominates
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
@@ -67,8 +71,11 @@ __device__ __forceinline__ int v_lds_off(int row, int ch) {
     return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * (ch & 3);
 }
 
-template <int DT, bool HAS_BIAS>
-__global__ __launch_bounds__(ATT_THREADS) void pgn_attn_fwd_d64_kernel(AttnArgs a) {
+template <int DT, bool HAS_BIAS, int NWAVES, int MINW>
+__global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_d64_kernel(AttnArgs a) {
+    constexpr int ATT_THREADS = NWAVES * 64;
+    constexpr int ATT_BM = NWAVES * 32;
+    constexpr int NSTAGE = 512 / ATT_THREADS;  // (row, chunk) pairs of each 64 x 8-chunk tile per thread
     // [buf][K|V][8 KiB] + [buf][64 floats of key bias]; one object so the base stays 16-byte aligned
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * ATT_TILE_ELEMS * 2 + 2 * ATT_BN * 4];
     float* bias_lds = reinterpret_cast<float*>(smem + 2 * 2 * ATT_TILE_ELEMS * 2);
@@ -92,25 +99,33 @@ __global__ __launch_bounds__(ATT_THREADS) void pgn_attn_fwd_d64_kernel(AttnArgs 
     for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const u16x8_t*>(qp + 16 * s);
 
     // ---- staging assignment: thread -> (key row, 16-byte chunk) of the K and V tiles
-    const int srow = tid >> 3, sch = tid & 7;
+    const int srow = tid >> 3, sch = tid & 7;   // + i * (ATT_THREADS / 8) rows for the i-th staged chunk
     const unsigned short* kp = a.k + b * a.k_sb + h * a.k_sh + sch * 8;
     const unsigned short* vp = a.v + b * a.v_sb + h * a.v_sh + sch * 8;
-    const int k_woff = k_lds_off(srow, sch), v_woff = v_lds_off(srow, sch);
+    int k_woff[NSTAGE], v_woff[NSTAGE];
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+        k_woff[i] = k_lds_off(srow + i * (ATT_THREADS / 8), sch);
+        v_woff[i] = v_lds_off(srow + i * (ATT_THREADS / 8), sch);
+    }
     const float* bp = HAS_BIAS ? a.bias + b * a.bias_sb : nullptr;
 
     const int nt = (a.Nk + ATT_BN - 1) / ATT_BN;
     const u16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    u16x8_t kreg, vreg;
+    u16x8_t kreg[NSTAGE], vreg[NSTAGE];
     float breg = 0.f;
     auto stage_load = [&](int t) {
-        const int key = t * ATT_BN + srow;
-        if (key < a.Nk) {
-            kreg = *reinterpret_cast<const u16x8_t*>(kp + (long long)key * a.k_sn);
-            vreg = *reinterpret_cast<const u16x8_t*>(vp + (long long)key * a.v_sn);
-        } else {
-            kreg = zero8;
-            vreg = zero8;
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int key = t * ATT_BN + srow + i * (ATT_THREADS / 8);
+            if (key < a.Nk) {
+                kreg[i] = *reinterpret_cast<const u16x8_t*>(kp + (long long)key * a.k_sn);
+                vreg[i] = *reinterpret_cast<const u16x8_t*>(vp + (long long)key * a.v_sn);
+            } else {
+                kreg[i] = zero8;
+                vreg[i] = zero8;
+            }
         }
         if constexpr (HAS_BIAS) {
             if (tid < ATT_BN) {
@@ -121,8 +136,11 @@ __global__ __launch_bounds__(ATT_THREADS) void pgn_attn_fwd_d64_kernel(AttnArgs 
     };
     auto stage_write = [&](int buf) {
         unsigned char* base = smem + buf * (2 * ATT_TILE_ELEMS * 2);
-        *reinterpret_cast<u16x8_t*>(base + k_woff) = kreg;
-        *reinterpret_cast<u16x8_t*>(base + ATT_TILE_ELEMS * 2 + v_woff) = vreg;
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            *reinterpret_cast<u16x8_t*>(base + k_woff[i]) = kreg[i];
+            *reinterpret_cast<u16x8_t*>(base + ATT_TILE_ELEMS * 2 + v_woff[i]) = vreg[i];
+        }
         if constexpr (HAS_BIAS) {
             if (tid < ATT_BN) bias_lds[buf * ATT_BN + tid] = breg;
         }
@@ -152,7 +170,10 @@ __global__ __launch_bounds__(ATT_THREADS) void pgn_attn_fwd_d64_kernel(AttnArgs 
     stage_write(0);
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
+    // One key tile.  MASKED is a compile-time tag so that the -inf masking of a ragged last tile costs nothing in the
+    // other iterations (the runtime form compiled to 31 v_cndmask per tile).
+    auto tile = [&](int t, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const int buf = t & 1;
         if (t + 1 < nt) stage_load(t + 1);
 
@@ -180,15 +201,13 @@ __global__ __launch_bounds__(ATT_THREADS) void pgn_attn_fwd_d64_kernel(AttnArgs 
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     sacc[kb][r] = fmaf(sacc[kb][r], a.c, bl[kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh]);
-        } else {
-            if (t == nt - 1 && (a.Nk & (ATT_BN - 1)) != 0) {
-                const int rem = a.Nk - t * ATT_BN;
+        } else if constexpr (MASKED) {
+            const int rem = a.Nk - t * ATT_BN;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= rem) sacc[kb][r] = -INFINITY;
-            }
+                for (int r = 0; r < 16; ++r)
+                    if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= rem) sacc[kb][r] = -INFINITY;
         }
 
         // ---- online softmax (one query row per lane; the two lane halves hold disjoint keys)
@@ -203,28 +222,36 @@ __global__ __launch_bounds__(ATT_THREADS) void pgn_attn_fwd_d64_kernel(AttnArgs 
         if (__any(m_new != m_run)) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cm);
             l_run *= alpha;
+            const f32x2_t alpha2 = {alpha, alpha};
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2_t o2 = {oacc[d][r], oacc[d][r + 1]};
+                    o2 *= alpha2;   // v_pk_mul_f32
+                    oacc[d][r] = o2[0];
+                    oacc[d][r + 1] = o2[1];
+                }
             m_run = m_new;
         }
         const float mc = m_run * cm;
-        float lsum = 0.f;
+        // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two scores per VALU instruction
+        const f32x2_t c2 = {HAS_BIAS ? 1.0f : a.c, HAS_BIAS ? 1.0f : a.c};
+        const f32x2_t nmc2 = {-mc, -mc};
+        f32x2_t lsum2 = {0.f, 0.f};
         u16x8_t pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p;
-                if constexpr (HAS_BIAS)
-                    p = __builtin_amdgcn_exp2f(sacc[kb][r] - mc);
-                else
-                    p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], a.c, -mc));
-                lsum += p;
-                pf[kb][r >> 3][r & 7] = Cvt<DT>::from_f32(p);
+            for (int r = 0; r < 16; r += 2) {
+                f32x2_t x = {sacc[kb][r], sacc[kb][r + 1]};
+                x = x * c2 + nmc2;
+                f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                lsum2 += p;
+                pf[kb][r >> 3][r & 7] = Cvt<DT>::from_f32(p[0]);
+                pf[kb][r >> 3][(r & 7) + 1] = Cvt<DT>::from_f32(p[1]);
             }
-        l_run += lsum;
+        l_run += lsum2[0] + lsum2[1];
 
         // ---- O^T += V^T P^T : A operand element j of lane half hh is key 16 s2 + 8 (j>>2) + 4 hh + (j&3)
 #pragma unroll
@@ -249,7 +276,12 @@ __global__ __launch_bounds__(ATT_THREADS) void pgn_attn_fwd_d64_kernel(AttnArgs 
 
         if (t + 1 < nt) stage_write(buf ^ 1);
         __syncthreads();
-    }
+    };
+
+    const bool ragged = (a.Nk & (ATT_BN - 1)) != 0;
+    const int nfull = ragged ? nt - 1 : nt;
+    for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+    if (ragged) tile(nt - 1, std::true_type{});
 
     // ---- epilogue: normalise and store (lane owns row qrow; 4 consecutive dims per 8-byte store)
     const float l_tot = xhalf_sum(l_run);
@@ -268,7 +300,12 @@ __global__ __launch_bounds__(ATT_THREADS) void pgn_attn_fwd_d64_kernel(AttnArgs 
     }
 }
 
+int g_attn_variant = 0;  // tuning hook (scripts/bench_kernels.py): 0 = heuristic, 1 = force 8 waves, 2 = force 4 waves
+
 }  // namespace
+
+// not part of the public ABI (absent from pigeon_hip.h): geometry override for A/B benchmarking in one process
+extern "C" void pgn_attention_tuning(int variant) { g_attn_variant = variant; }
 
 extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H,
                                  int Nq, int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb,
@@ -285,7 +322,15 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
         if (st[i] < 0 || (st[i] & 7) != 0) return PGN_ERR_INVALID;
     if (!pgn_aligned(q, 16) || !pgn_aligned(k, 16) || !pgn_aligned(v, 16) || !pgn_aligned(out, 16)) return PGN_ERR_INVALID;
     if (key_bias != nullptr && bias_sb < 0) return PGN_ERR_INVALID;
-    const long long nqt = (Nq + ATT_BM - 1) / ATT_BM;
+    // Geometry: 4 waves x 32 rows, two workgroups per CU (2 waves per SIMD from DIFFERENT workgroups, so one
+    // workgroup's barrier / prologue / epilogue hides behind the other's main loop).  Measured on MI355X at every
+    // SDXL shape (scripts/bench_kernels.py): 4 waves beat the 8-wave 256-row geometry by 4 % (self, N 4096) to
+    // 30 % (cross, Nk 256); the 8-wave form stays reachable through pgn_attention_tuning for A/B runs.
+    int nw = 4;
+    if (g_attn_variant == 1) nw = 8;
+    if (g_attn_variant == 2) nw = 4;
+    const int bm = nw * 32;
+    const long long nqt = (Nq + bm - 1) / bm;
     const long long blocks = (long long)B * H * nqt;
     if (blocks > 0x7fffffffLL) return PGN_ERR_UNSUPPORTED;
 
@@ -297,14 +342,20 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     a.v_sb = v_sb; a.v_sn = v_sn; a.v_sh = v_sh; a.o_sb = o_sb; a.o_sn = o_sn; a.o_sh = o_sh; a.bias_sb = bias_sb;
     a.c = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)blocks), block(ATT_THREADS);
+    const dim3 grid((unsigned)blocks), block(nw * 64);
+#define PGN_ATT_LAUNCH(DT, BIAS)                                                                          \
+    do {                                                                                                  \
+        if (nw == 8) hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<DT, BIAS, 8, 2>), grid, block, 0, s, a);   \
+        else hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<DT, BIAS, 4, 2>), grid, block, 0, s, a);           \
+    } while (0)
     if (dtype == PGN_BF16) {
-        if (key_bias != nullptr) hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<PGN_BF16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<PGN_BF16, false>), grid, block, 0, s, a);
+        if (key_bias != nullptr) PGN_ATT_LAUNCH(PGN_BF16, true);
+        else PGN_ATT_LAUNCH(PGN_BF16, false);
     } else {
-        if (key_bias != nullptr) hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<PGN_F16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<PGN_F16, false>), grid, block, 0, s, a);
+        if (key_bias != nullptr) PGN_ATT_LAUNCH(PGN_F16, true);
+        else PGN_ATT_LAUNCH(PGN_F16, false);
     }
+#undef PGN_ATT_LAUNCH
     PGN_LAUNCH_CHECK();
     return PGN_OK;
 }

@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""A few launches of the attention kernel at one SDXL shape (for rocprofv3 --pmc passes)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pigeon_amd import ops, _lib
+shape = os.environ.get("SHAPE", "self_L1")
+H, Nq, Nk = {"self_L1": (10, 4096, 4096), "self_L2": (20, 1024, 1024), "cross_L1": (10, 4096, 256), "cross_L2": (20, 1024, 256)}[shape]
+Bp = 32
+_lib.load().pgn_attention_tuning(int(os.environ.get("VAR", "0")))
+q = torch.randn(Bp, Nq, H * 64, device="cuda").bfloat16(); k = torch.randn(Bp, Nk, H * 64, device="cuda").bfloat16(); v = torch.randn(Bp, Nk, H * 64, device="cuda").bfloat16()
+for _ in range(int(os.environ.get("ITERS", "3"))):
+    o = ops.attention(q, k, v, H)
+torch.cuda.synchronize()

@@ -22,19 +22,25 @@ for name, H, Nq, Nk in (("self_L1", 10, 4096, 4096), ("self_L2", 20, 1024, 1024)
                         ("self_L1_ragged", 10, 3952, 3952), ("self_L2_ragged", 20, 988, 988)):
     C = H * 64
     q = torch.randn(Bp, Nq, C, device=dev).bfloat16(); k = torch.randn(Bp, Nk, C, device=dev).bfloat16(); v = torch.randn(Bp, Nk, C, device=dev).bfloat16()
-    t = timeit(lambda: ops.attention(q, k, v, H))
     fl = 4.0 * Bp * H * Nq * Nk * 64
-    res.append((f"attn_{name}", t * 1e6, fl / t / 1e12, "TFLOP/s"))
+    from pigeon_amd import _lib
+    for var, vn in ((1, "8w"), (2, "4w")):
+        _lib.load().pgn_attention_tuning(var)
+        t = timeit(lambda: ops.attention(q, k, v, H))
+        res.append((f"attn_{name}_{vn}", t * 1e6, fl / t / 1e12, "TFLOP/s"))
+    _lib.load().pgn_attention_tuning(0)
     tq = q.view(Bp, Nq, H, 64).transpose(1, 2); tk = k.view(Bp, Nk, H, 64).transpose(1, 2); tv = v.view(Bp, Nk, H, 64).transpose(1, 2)
-    t2 = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(tq, tk, tv), iters=5, warm=2)
-    res.append((f"  torch_sdpa_{name}", t2 * 1e6, fl / t2 / 1e12, "TFLOP/s"))
+    if os.environ.get("SDPA"):
+        t2 = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(tq, tk, tv), iters=5, warm=2)
+        res.append((f"  torch_sdpa_{name}", t2 * 1e6, fl / t2 / 1e12, "TFLOP/s"))
 for C, HW in ((320, 16384), (640, 16384), (960, 16384), (640, 4096), (1280, 4096), (1920, 4096), (1280, 1024), (2560, 1024)):
     x = torch.randn(Bp, C, HW, device=dev).bfloat16(); w = torch.randn(C, device=dev).bfloat16(); b = torch.randn(C, device=dev).bfloat16()
     t = timeit(lambda: ops.group_norm_silu(x, 32, w, b, 1e-5, True))
     res.append((f"gn_silu_{C}x{HW}", t * 1e6, x.numel() * 4 / t / 1e9, "GB/s"))
-    gn = torch.nn.GroupNorm(32, C).to(dev).bfloat16()
-    t2 = timeit(lambda: torch.nn.functional.silu(gn(x)), iters=5, warm=2)
-    res.append((f"  torch_gn_silu_{C}x{HW}", t2 * 1e6, x.numel() * 4 / t2 / 1e9, "GB/s"))
+    if os.environ.get("TORCHGN"):
+        gn = torch.nn.GroupNorm(32, C).to(dev).bfloat16()
+        t2 = timeit(lambda: torch.nn.functional.silu(gn(x)), iters=5, warm=2)
+        res.append((f"  torch_gn_silu_{C}x{HW}", t2 * 1e6, x.numel() * 4 / t2 / 1e9, "GB/s"))
 for B in (16, 128):
     npred = torch.randn(2 * B, 4, 128, 128, device=dev).bfloat16(); lat = torch.randn(B, 4, 128, 128, device=dev)
     t = timeit(lambda: ops.cfg_ddim_step(npred, lat, 7.0, 0.9, 0.43, 0.92, 0.39))
