@@ -34,6 +34,23 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # HBM3E peak
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc.json, written by
+    scripts/profile_bench.sh + scripts/profile_summary.py: separate FETCH_SIZE / WRITE_SIZE passes over this same
+    command, gfx950 FETCH_SIZE x2 correction).  Counters cannot be collected from inside the timed run, so the figure
+    is read from the file and its name is reported beside it; None when no summary exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        data = json.load(fh)
+    for name, e in data.items():
+        if kernel in name and "hbm_bytes_per_launch" in e:
+            return e["hbm_bytes_per_launch"]["total"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 class LaunchTimer:
     """HIP-event bracket around every C-ABI launch (events on torch's current stream = the launch stream)."""
 
@@ -199,9 +216,11 @@ def main():
     if "attention" in agg:
         n, work, secs = agg["attention"]
         ach = work / secs / 1e12
+        traffic, src = pmc_traffic("pgn_attn_fwd_d64_kernel")
         roofline = {"kernel": "pgn_attn_fwd_d64_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                    "launches": n, "avg_launch_us": secs / n * 1e6, "flop_per_launch": work / n}
+                    "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": src, "launches": n, "avg_launch_us": secs / n * 1e6,
+                    "flop_per_launch": work / n}
 
     state["phase"] = "cpu baseline"
     cpu = None
