@@ -8,7 +8,13 @@ __version__ = "0.1.0"
 
 import os as _os
 
-# MIOpen (3x3 convs of the UNet / VAE, reached through torch) otherwise benchmarks every solver the first time it sees
-# a shape: ~80 s per model on a fresh machine.  Immediate-mode selection gives the same steady-state speed here.
-_os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+# MIOpen (3x3 convs of the UNet / VAE, reached through torch).  torch's default immediate mode never benchmarks, but its
+# heuristic picks a 300-500 TFLOP/s solver for the SDXL shapes where a find reaches 500-900 (CK grouped-conv xdlops).
+# A find costs ~4 minutes per model on a fresh machine, so it is done once (scripts/tune_miopen.py) and its text
+# find-db ships in-tree: immediate mode reads it and picks the measured-best solver with no find at run time.  Shapes
+# that are not in the db (other batch sizes / resolutions) fall back to the heuristic.
+_db = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
+if _os.path.isdir(_db):
+    _os.environ.setdefault("MIOPEN_USER_DB_PATH", _db)
+_os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # if a caller turns cudnn.benchmark on: db hit or heuristic, no search
 _os.environ.setdefault("MIOPEN_LOG_LEVEL", "3")
