@@ -144,6 +144,31 @@ int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, in
                       int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
                       int64_t o_sh, const float* key_bias, int64_t bias_sb, float scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * GEGLU gate of the transformer feed-forward: y[m, j] = h[m, j] * gelu(h[m, D + j]), exact (erf) GELU.
+ * Replaces diffusers 0.27.2 GEGLU.forward (`hidden, gate = proj(x).chunk(2, dim=-1); hidden * F.gelu(gate)`)
+ * inside BasicTransformerBlock.ff, reached through `self.unet(...)` at lavit_for_pigeon.py:752-757 — in torch
+ * a strided gelu launch plus a multiply launch.  Both torch ops round to the io type, and so does this
+ * kernel (gelu in fp32 -> round -> product in fp32 -> round): bit-exact with the two-op form.
+ * h: [M, 2*D] rows of ld_h elements; y: [M, D] rows of ld_y elements; D % 8 == 0; bf16 / f16.
+ * Algorithmic bytes: M*D*3*sizeof(elem).
+ */
+int pgn_geglu(const void* h, void* y, int dtype, int64_t M, int D, int64_t ld_h, int64_t ld_y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (residual add +) LayerNorm over the last dimension, one pass.
+ * Replaces the `attn(...) + hidden_states` / `ff(...) + hidden_states` adds of diffusers 0.27.2
+ * BasicTransformerBlock.forward together with the norm1/norm2/norm3 LayerNorm that consumes each sum
+ * (torch.nn.functional.layer_norm, run in fp32 by autocast; reached from lavit_for_pigeon.py:752-757):
+ *   s = x + residual (rounded to the io type, written to sum_out)      [skipped when residual == NULL]
+ *   y = (s - mean(s)) * rsqrt(var(s) + eps) * gamma + beta             fp32 statistics, one rounding
+ * x, residual, sum_out, y: [M, C] contiguous, bf16 / f16; gamma/beta: affine_dtype [C] or both NULL.
+ * residual and sum_out are given together or both NULL.  C % 8 == 0, C <= 4096.
+ * Algorithmic bytes: M*C*sizeof(elem) * (2 without residual, 4 with).
+ */
+int pgn_add_layernorm(const void* x, const void* residual, void* sum_out, void* y, const void* gamma,
+                      const void* beta, int dtype, int affine_dtype, int64_t M, int C, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,3 +147,21 @@ def attention_ref(q, k, v, heads, scale=None, key_bias=None, out_dtype=None):
     p = torch.softmax(s, dim=-1)
     o = torch.matmul(p, vh).transpose(1, 2).reshape(B, Nq, C)
     return o.to(out_dtype or q.dtype)
+
+
+# ---- transformer-block row kernels -------------------------------------------------------------------------
+def geglu_ref(h: torch.Tensor) -> torch.Tensor:
+    """diffusers 0.27.2 GEGLU.forward after the projection: `hidden, gate = h.chunk(2, dim=-1); hidden * F.gelu(gate)`,
+    evaluated in h's own dtype (bf16 under autocast: gelu rounds, the product rounds).  PARITY UNPINNED."""
+    hidden, gate = h.chunk(2, dim=-1)
+    return hidden * F.gelu(gate)
+
+
+def add_layer_norm_ref(x: torch.Tensor, residual: Optional[torch.Tensor], weight, bias, eps: float = 1e-5):
+    """`s = x + residual` in the io dtype (diffusers BasicTransformerBlock residual adds), then F.layer_norm in fp32
+    (autocast runs layer_norm in fp32) rounded once to the io dtype.  Returns (s, y, y_fp32).  PARITY UNPINNED."""
+    s = x if residual is None else x + residual
+    w = None if weight is None else weight.float()
+    b = None if bias is None else bias.float()
+    y32 = F.layer_norm(s.float(), (s.shape[-1],), w, b, eps)
+    return s, y32.to(x.dtype), y32

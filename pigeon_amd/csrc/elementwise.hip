@@ -1,0 +1,204 @@
+// Row-wise HBM-bound kernels of the transformer blocks inside the UNet (see include/pigeon_hip.h:
+// pgn_geglu, pgn_add_layernorm).  Both replace chains of torch elementwise / norm launches that diffusers'
+// BasicTransformerBlock issues between its GEMMs (reached from Pigeon/models/lavit_for_pigeon.py:752-757):
+//   GEGLU           proj(x).chunk(2) -> hidden * F.gelu(gate)      : strided gelu launch + mul launch  -> one pass
+//   add + LayerNorm attn_out + hidden_states ; LayerNorm(...)      : add launch + norm launch          -> one pass
+// One 16-byte vector per lane per access, rows are contiguous, statistics in fp32 with wave64 shuffles only
+// (one wavefront owns one row: no LDS, no barrier).
+#include "pgn_common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+template <int DT>
+__device__ __forceinline__ void unpack8(const u16x8_t& v, float (&f)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = Cvt<DT>::to_f32(v[j]);
+}
+template <int DT>
+__device__ __forceinline__ u16x8_t pack8(const float (&f)[8]) {
+    u16x8_t v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = Cvt<DT>::from_f32(f[j]);
+    return v;
+}
+
+// ---- GEGLU -------------------------------------------------------------------------------------
+// torch semantics, op by op (both ops run in fp32 "opmath" and round to the io type):
+//   g = round(0.5 * gate * (1 + erf(gate / sqrt(2))))        F.gelu(gate), approximate='none'
+//   y = round(hidden * g)
+template <int DT>
+__global__ __launch_bounds__(EW_THREADS) void pgn_geglu_kernel(const unsigned short* __restrict__ h,
+                                                               unsigned short* __restrict__ y, long long M, int D8,
+                                                               long long ld_h, long long ld_y) {
+    const long long total = M * D8;
+    const long long step = (long long)gridDim.x * EW_THREADS;
+    for (long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += step) {
+        const long long m = i / D8;
+        const int c = (int)(i - m * D8) * 8;
+        const unsigned short* row = h + m * ld_h;
+        const u16x8_t xv = *reinterpret_cast<const u16x8_t*>(row + c);
+        const u16x8_t gv = *reinterpret_cast<const u16x8_t*>(row + (long long)D8 * 8 + c);
+        float x[8], g[8];
+        unpack8<DT>(xv, x);
+        unpack8<DT>(gv, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float ge = 0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752440f));
+            const float gr = Cvt<DT>::to_f32(Cvt<DT>::from_f32(ge));
+            x[j] = x[j] * gr;
+        }
+        *reinterpret_cast<u16x8_t*>(y + m * ld_y + c) = pack8<DT>(x);
+    }
+}
+
+// ---- (residual add +) LayerNorm ------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ float ld_param(const void* p, int adt, int c) {
+    if (adt == PGN_F32) return reinterpret_cast<const float*>(p)[c];
+    const unsigned short hh = reinterpret_cast<const unsigned short*>(p)[c];
+    return adt == PGN_BF16 ? Cvt<PGN_BF16>::to_f32(hh) : Cvt<PGN_F16>::to_f32(hh);
+}
+
+// One wavefront per row, R vectors of 8 elements per lane held in registers (C <= 512 * R).
+template <int DT, int R, bool HAS_RES>
+__global__ __launch_bounds__(EW_THREADS) void pgn_add_layernorm_kernel(
+    const unsigned short* __restrict__ x, const unsigned short* __restrict__ res, unsigned short* __restrict__ sum_out,
+    unsigned short* __restrict__ y, const void* __restrict__ gamma, const void* __restrict__ beta, int adt, long long M,
+    int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (EW_THREADS / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;   // whole wavefront leaves together: no barrier in this kernel
+    const int C8 = C >> 3;
+    const unsigned short* xr = x + row * C;
+    float f[R][8];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int v = lane + 64 * r;
+        if (v < C8) {
+            unpack8<DT>(*reinterpret_cast<const u16x8_t*>(xr + 8 * v), f[r]);
+            if constexpr (HAS_RES) {
+                float g[8];
+                unpack8<DT>(*reinterpret_cast<const u16x8_t*>(res + row * C + 8 * v), g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[r][j] += g[j];   // one fp32 add, rounded below: torch's bf16 add
+                const u16x8_t hv = pack8<DT>(f[r]);
+                *reinterpret_cast<u16x8_t*>(sum_out + row * C + 8 * v) = hv;
+                unpack8<DT>(hv, f[r]);                          // the norm sees the rounded sum, as in the reference
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += f[r][j];
+        }
+    }
+    const float inv_c = 1.0f / (float)C;
+    const float mean = wave_sum64(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (lane + 64 * r < C8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = f[r][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum64(q) * inv_c + eps);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int v = lane + 64 * r;
+        if (v < C8) {
+            float ga[8], be[8];
+            if (gamma == nullptr) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ga[j] = 1.0f; be[j] = 0.0f; }
+            } else if (adt == DT) {   // the usual case: parameters stored like the activations, one 16-byte load each
+                unpack8<DT>(*reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(gamma) + 8 * v), ga);
+                unpack8<DT>(*reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(beta) + 8 * v), be);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    ga[j] = ld_param(gamma, adt, 8 * v + j);
+                    be[j] = ld_param(beta, adt, 8 * v + j);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[r][j] = (f[r][j] - mean) * rstd * ga[j] + be[j];
+            *reinterpret_cast<u16x8_t*>(y + row * C + 8 * v) = pack8<DT>(f[r]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int pgn_geglu(const void* h, void* y, int dtype, int64_t M, int D, int64_t ld_h, int64_t ld_y,
+                         void* stream) {
+    if (h == nullptr || y == nullptr) return PGN_ERR_INVALID;
+    if (M <= 0 || D <= 0 || ld_h < 2LL * D || ld_y < D) return PGN_ERR_INVALID;
+    if (dtype != PGN_BF16 && dtype != PGN_F16) return PGN_ERR_UNSUPPORTED;
+    if ((D & 7) != 0 || (ld_h & 7) != 0 || (ld_y & 7) != 0 || !pgn_aligned(h, 16) || !pgn_aligned(y, 16))
+        return PGN_ERR_UNSUPPORTED;
+    const long long total = (long long)M * (D / 8);
+    long long blocks = (total + EW_THREADS - 1) / EW_THREADS;
+    if (blocks > 256LL * 64) blocks = 256LL * 64;   // grid-stride beyond 64 workgroups per CU
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)blocks), block(EW_THREADS);
+    if (dtype == PGN_BF16)
+        hipLaunchKernelGGL((pgn_geglu_kernel<PGN_BF16>), grid, block, 0, s, (const unsigned short*)h, (unsigned short*)y,
+                           (long long)M, D / 8, (long long)ld_h, (long long)ld_y);
+    else
+        hipLaunchKernelGGL((pgn_geglu_kernel<PGN_F16>), grid, block, 0, s, (const unsigned short*)h, (unsigned short*)y,
+                           (long long)M, D / 8, (long long)ld_h, (long long)ld_y);
+    PGN_LAUNCH_CHECK();
+    return PGN_OK;
+}
+
+extern "C" int pgn_add_layernorm(const void* x, const void* residual, void* sum_out, void* y, const void* gamma,
+                                 const void* beta, int dtype, int affine_dtype, int64_t M, int C, float eps,
+                                 void* stream) {
+    if (x == nullptr || y == nullptr) return PGN_ERR_INVALID;
+    if ((residual == nullptr) != (sum_out == nullptr)) return PGN_ERR_INVALID;
+    if ((gamma == nullptr) != (beta == nullptr)) return PGN_ERR_INVALID;
+    if (M <= 0 || C <= 0 || !(eps >= 0.f)) return PGN_ERR_INVALID;
+    if (gamma != nullptr && pgn_dtype_size(affine_dtype) == 0) return PGN_ERR_INVALID;
+    if (dtype != PGN_BF16 && dtype != PGN_F16) return PGN_ERR_UNSUPPORTED;
+    if ((C & 7) != 0 || C > 4096) return PGN_ERR_UNSUPPORTED;
+    if (!pgn_aligned(x, 16) || !pgn_aligned(y, 16) || !pgn_aligned(residual, 16) || !pgn_aligned(sum_out, 16))
+        return PGN_ERR_UNSUPPORTED;
+    const long long blocks = (M + (EW_THREADS / 64) - 1) / (EW_THREADS / 64);
+    if (blocks > 0x7fffffffLL) return PGN_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)blocks), block(EW_THREADS);
+    const int r = (C / 8 + 63) / 64;   // vectors per lane: 1..8
+#define PGN_LN_LAUNCH(DT, R, RES)                                                                             \
+    hipLaunchKernelGGL((pgn_add_layernorm_kernel<DT, R, RES>), grid, block, 0, s, (const unsigned short*)x,    \
+                       (const unsigned short*)residual, (unsigned short*)sum_out, (unsigned short*)y, gamma,  \
+                       beta, affine_dtype, (long long)M, C, eps)
+#define PGN_LN_R(DT, RES)                       \
+    do {                                        \
+        if (r <= 1) PGN_LN_LAUNCH(DT, 1, RES);  \
+        else if (r <= 2) PGN_LN_LAUNCH(DT, 2, RES); \
+        else if (r <= 3) PGN_LN_LAUNCH(DT, 3, RES); \
+        else if (r <= 4) PGN_LN_LAUNCH(DT, 4, RES); \
+        else if (r <= 6) PGN_LN_LAUNCH(DT, 6, RES); \
+        else PGN_LN_LAUNCH(DT, 8, RES);         \
+    } while (0)
+    if (dtype == PGN_BF16) {
+        if (residual) PGN_LN_R(PGN_BF16, true);
+        else PGN_LN_R(PGN_BF16, false);
+    } else {
+        if (residual) PGN_LN_R(PGN_F16, true);
+        else PGN_LN_R(PGN_F16, false);
+    }
+#undef PGN_LN_R
+#undef PGN_LN_LAUNCH
+    PGN_LAUNCH_CHECK();
+    return PGN_OK;
+}

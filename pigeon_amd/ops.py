@@ -242,6 +242,60 @@ def group_norm_silu(x: torch.Tensor, num_groups: int, weight: Optional[torch.Ten
 
 
 # ------------------------------------------------------------------------------------------------
+def geglu(h: torch.Tensor) -> torch.Tensor:
+    """hidden * gelu(gate) with [hidden | gate] = h.chunk(2, dim=-1) (diffusers GEGLU.forward) in one launch."""
+    lib = _lib.load()
+    _dev(h)
+    if h.shape[-1] % 2:
+        raise ValueError("geglu expects an even last dimension")
+    D = h.shape[-1] // 2
+    h2 = h.reshape(-1, 2 * D)
+    if h2.stride(1) != 1:
+        h2 = h2.contiguous()
+    M = h2.shape[0]
+    y = torch.empty(h.shape[:-1] + (D,), dtype=h.dtype, device=h.device)
+
+    def run():
+        rc = lib.pgn_geglu(_ptr(h2), _ptr(y), _dt(h), M, D, h2.stride(0), D, _stream())
+        _lib.check(rc, "pgn_geglu")
+
+    _launch("geglu", float(3 * M * D * h.element_size()), run)
+    return y
+
+
+def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: Optional[torch.Tensor],
+                   bias: Optional[torch.Tensor], eps: float = 1e-5):
+    """LayerNorm over the last dim of (x + residual).  Returns (sum, normed); sum is x itself when residual is None."""
+    lib = _lib.load()
+    _dev(x, residual, weight, bias)
+    C = x.shape[-1]
+    x = x.contiguous()
+    M = x.numel() // C
+    if residual is not None:
+        if residual.shape != x.shape or residual.dtype != x.dtype:
+            raise ValueError("residual must match x")
+        residual = residual.contiguous()
+    if (weight is None) != (bias is None):
+        raise ValueError("weight and bias must both be given or both be None")
+    adt = PGN_F32
+    if weight is not None:
+        if weight.numel() != C or bias.numel() != C or weight.dtype != bias.dtype:
+            raise ValueError("affine parameters must be [C] and share a dtype")
+        weight, bias = weight.contiguous(), bias.contiguous()
+        adt = _dt(weight)
+    y = torch.empty_like(x)
+    s = torch.empty_like(x) if residual is not None else None
+
+    def run():
+        rc = lib.pgn_add_layernorm(_ptr(x), _ptr(residual), _ptr(s), _ptr(y), _ptr(weight), _ptr(bias), _dt(x), adt,
+                                   M, C, float(eps), _stream())
+        _lib.check(rc, "pgn_add_layernorm")
+
+    _launch("layernorm", float(x.numel() * x.element_size() * (4 if residual is not None else 2)), run)
+    return (s if residual is not None else x), y
+
+
+# ------------------------------------------------------------------------------------------------
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
               key_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(q k^T * scale + key_bias) v per head, replacing xformers.ops.memory_efficient_attention.

@@ -18,8 +18,8 @@ from typing import Any, Dict, Optional, Tuple, Union
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from . import ops
 from .attention_processor import Attention, HipAttnProcessor
 from .layers import (Downsample2D, GroupNormAct, ResnetBlock2D, TimestepEmbedding, Upsample2D, timestep_embedding)
 
@@ -63,8 +63,8 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        x, gate = self.proj(x).chunk(2, dim=-1)
-        return x * F.gelu(gate)
+        # `hidden, gate = proj(x).chunk(2, dim=-1); hidden * F.gelu(gate)` (diffusers GEGLU.forward) in one launch
+        return ops.geglu(self.proj(x))
 
 
 class FeedForward(nn.Module):
@@ -88,12 +88,22 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim, eps=1e-5)
         self.ff = FeedForward(dim)
 
-    def forward(self, hidden_states, encoder_hidden_states=None, encoder_attention_mask=None, attention_mask=None):
-        hidden_states = self.attn1(self.norm1(hidden_states), attention_mask=attention_mask) + hidden_states
-        hidden_states = self.attn2(self.norm2(hidden_states), encoder_hidden_states=encoder_hidden_states,
-                                   attention_mask=encoder_attention_mask) + hidden_states
-        hidden_states = self.ff(self.norm3(hidden_states)) + hidden_states
-        return hidden_states
+    def forward(self, hidden_states, encoder_hidden_states=None, encoder_attention_mask=None, attention_mask=None,
+                pending=None, defer_add=False):
+        """diffusers BasicTransformerBlock.forward: x += attn1(norm1(x)); x += attn2(norm2(x), ctx); x += ff(norm3(x)).
+        Each residual add is fused with the LayerNorm that consumes the sum (ops.add_layer_norm, one pass).
+        `pending` is a tensor still to be added to `hidden_states` (the previous block's feed-forward output);
+        with `defer_add` the block returns (x, ff_out) and leaves the last add to its consumer."""
+        n1, n2, n3 = self.norm1, self.norm2, self.norm3
+        hidden_states, h = ops.add_layer_norm(hidden_states, pending, n1.weight, n1.bias, n1.eps)
+        a = self.attn1(h, attention_mask=attention_mask)
+        hidden_states, h = ops.add_layer_norm(a, hidden_states, n2.weight, n2.bias, n2.eps)
+        a = self.attn2(h, encoder_hidden_states=encoder_hidden_states, attention_mask=encoder_attention_mask)
+        hidden_states, h = ops.add_layer_norm(a, hidden_states, n3.weight, n3.bias, n3.eps)
+        f = self.ff(h)
+        if defer_add:
+            return hidden_states, f
+        return f + hidden_states
 
 
 class Transformer2DModel(nn.Module):
@@ -122,8 +132,11 @@ class Transformer2DModel(nn.Module):
         else:
             hidden_states = self.proj_in(hidden_states)
             hidden_states = hidden_states.permute(0, 2, 3, 1).reshape(b, h * w, -1)
+        pending = None
         for block in self.transformer_blocks:
-            hidden_states = block(hidden_states, encoder_hidden_states, encoder_attention_mask, attention_mask)
+            hidden_states, pending = block(hidden_states, encoder_hidden_states, encoder_attention_mask,
+                                           attention_mask, pending=pending, defer_add=True)
+        hidden_states = pending + hidden_states
         if self.use_linear_projection:
             hidden_states = self.proj_out(hidden_states)
             hidden_states = hidden_states.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous()

@@ -52,3 +52,12 @@ def test_argument_validation_happens_before_any_launch():
     # head_dim other than 64 -> unsupported, 3-channel groups that do not divide -> invalid
     assert lib.pgn_attention_fwd(p16, p16, p16, p16, 1, 1, 1, 1, 1, 40, *([8] * 12), None, 0, 0.1, None) == -2
     assert lib.pgn_groupnorm_silu(p16, 1, p16, 1, None, None, 1, 1, 30, 16, 32, 1e-5, 1, None) == -1
+    # row kernels: nulls -> invalid; D / C not a multiple of 8, fp32 io, C > 4096 -> unsupported
+    assert lib.pgn_geglu(None, None, 1, 4, 8, 16, 8, None) == -1
+    assert lib.pgn_geglu(p16, p16, 1, 4, 12, 24, 12, None) == -2
+    assert lib.pgn_geglu(p16, p16, 0, 4, 8, 16, 8, None) == -2
+    assert lib.pgn_geglu(p16, p16, 1, 4, 8, 8, 8, None) == -1            # leading dimension < 2 D
+    assert lib.pgn_add_layernorm(None, None, None, None, None, None, 1, 1, 4, 8, 1e-5, None) == -1
+    assert lib.pgn_add_layernorm(p16, p16, None, p16, None, None, 1, 1, 4, 8, 1e-5, None) == -1   # residual w/o sum_out
+    assert lib.pgn_add_layernorm(p16, None, None, p16, None, None, 1, 1, 4, 12, 1e-5, None) == -2
+    assert lib.pgn_add_layernorm(p16, None, None, p16, None, None, 1, 1, 4, 8192, 1e-5, None) == -2

@@ -279,3 +279,92 @@ def test_attention_full_size_properties(ops):
     sl = slice(h * 64, (h + 1) * 64)
     want = ops_ref.attention_ref(q[b:b + 1, :, sl].cpu(), k[b:b + 1, :, sl].cpu(), v1[b:b + 1, :, sl].cpu(), 1).float()
     assert (o1[b:b + 1, :, sl].cpu() - want).abs().max().item() < 2.0 ** -7
+
+
+# ---- transformer-block row kernels -------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 1024, 2 * 5120), (3, 17, 2 * 2560), (1, 1, 16), (4096 + 3, 2 * 40)])
+def test_geglu_bit_exact(ops, dtype, shape):
+    g = torch.Generator().manual_seed(shape[-1])
+    h = (torch.randn(shape, generator=g) * 2.5).to(dtype)
+    want = ops_ref.geglu_ref(h)                      # torch CPU: the same two roundings (gelu, product)
+    got = ops.geglu(h.to(DEV))
+    assert got.shape == want.shape and got.dtype == dtype
+    # the device erf (ocml) and the host libm erf may differ by an fp32 ulp before the rounding to 16 bits:
+    # bit-exact against torch's own two-op form ON THE DEVICE, <= 1 ulp of the io type against the CPU oracle
+    hidden, gate = h.to(DEV).chunk(2, dim=-1)
+    dev_ref = hidden * torch.nn.functional.gelu(gate)
+    ulp = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+    if dtype == torch.bfloat16:      # the reference's dtype (lavit_for_pigeon.py:706 autocast bf16)
+        assert torch.equal(got, dev_ref)
+    else:                            # f16 keeps 3 more bits: an fp32-ulp difference between erf builds shows up, rarely
+        assert (got != dev_ref).float().mean().item() < 1e-3
+        assert bool(((got.float() - dev_ref.float()).abs()
+                     <= 2 * ulp * dev_ref.float().abs() + 2e-7 * (hidden.float() * gate.float()).abs() + 1e-6).all())
+    err = (got.cpu().float() - want.float()).abs()
+    # 1 + erf(x) cancels for x << 0, so two fp32 erf implementations (host libm, device ocml) differ there by up to
+    # ~1e-7 ABSOLUTE in (1 + erf): |hidden * gate| * 2e-7 covers it (visible in f16 only)
+    hid, gat = h.float().chunk(2, dim=-1)
+    assert bool((err <= 2 * ulp * want.float().abs() + 2e-7 * (hid * gat).abs() + 1e-6).all())
+    assert (got.cpu() != want).float().mean().item() < (0.01 if dtype == torch.bfloat16 else 0.05)
+
+
+def test_geglu_strided_rows(ops):
+    # rows of a wider buffer (leading dimension > 2 D): no copy, same result
+    big = torch.randn(64, 3 * 256, device=DEV).to(torch.bfloat16)
+    h = big[:, :512]
+    hidden, gate = h.chunk(2, dim=-1)
+    assert torch.equal(ops.geglu(h), hidden * torch.nn.functional.gelu(gate))
+
+
+LN_CASES = [(2, 1024, 1280), (2, 4096, 640), (5, 7, 320), (3, 1, 8), (2, 33, 2560), (1, 9, 4096), (2, 5, 1408)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", LN_CASES, ids=[f"{s[0]}x{s[1]}x{s[2]}" for s in LN_CASES])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_add_layernorm_matches_oracle(ops, dtype, shape, with_res):
+    g = torch.Generator().manual_seed(shape[-1] + shape[1])
+    C = shape[-1]
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3 * torch.randn(1, 1, C, generator=g)).to(dtype)
+    r = (torch.randn(shape, generator=g) * 0.7).to(dtype) if with_res else None
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype)
+    b = (0.2 * torch.randn(C, generator=g)).to(dtype)
+    want_s, want_y, want32 = ops_ref.add_layer_norm_ref(x, r, w, b, 1e-5)
+    got_s, got_y = ops.add_layer_norm(x.to(DEV), None if r is None else r.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
+    assert torch.equal(got_s.cpu(), want_s)          # the residual sum is one exact fp32 add + one rounding
+    ulp = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+    err = (got_y.cpu().float() - want32).abs()
+    # fp32 statistics both sides, one rounding to the io type: within 1 ulp of the io type of the fp32 oracle
+    assert bool((err <= ulp * want32.abs() + 4 * ulp * 2.0 ** -7).all()), err.max().item()
+    assert (got_y.cpu() != want_y).float().mean().item() < 0.02
+
+
+def test_add_layernorm_no_affine_and_fp32_params(ops):
+    x = torch.randn(4, 10, 640).to(torch.bfloat16)
+    _, y = ops.add_layer_norm(x.to(DEV), None, None, None, 1e-6)
+    want = torch.nn.functional.layer_norm(x.float(), (640,), None, None, 1e-6)
+    assert (y.cpu().float() - want).abs().max().item() < 2.0 ** -6
+    w, b = torch.rand(640) + 0.5, torch.randn(640)
+    _, y = ops.add_layer_norm(x.to(DEV), None, w.to(DEV), b.to(DEV), 1e-5)
+    want = torch.nn.functional.layer_norm(x.float(), (640,), w, b, 1e-5)
+    assert (y.cpu().float() - want).abs().max().item() < 2.0 ** -5
+
+
+def test_row_kernels_full_size_properties(ops):
+    # BASELINE config-2 sizes (B' = 32, level-2 tokens: M = 32768 rows): size-independent properties.
+    M, C = 32 * 1024, 1280
+    x = (torch.randn(M, C, device=DEV) * 2 + 0.5).to(torch.bfloat16)
+    r = torch.randn(M, C, device=DEV).to(torch.bfloat16)
+    s, y = ops.add_layer_norm(x, r, None, None, 1e-5)
+    assert torch.equal(s, x + r)
+    yf = y.float()
+    assert yf.mean(-1).abs().max().item() < 4e-3 and (yf.var(-1, unbiased=False) - 1).abs().max().item() < 1e-2
+    h = torch.randn(M, 2 * 4 * C, device=DEV).to(torch.bfloat16)
+    out = ops.geglu(h)
+    # gate -> +large: gelu(g) = g, so geglu(h) = hidden * gate there; gate = 0 -> 0
+    h2 = h.clone()
+    h2[:, 4 * C:] = 0
+    assert ops.geglu(h2).abs().max().item() == 0
+    hidden, gate = h.chunk(2, dim=-1)
+    assert torch.equal(out, hidden * torch.nn.functional.gelu(gate))
