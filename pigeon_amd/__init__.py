@@ -18,3 +18,22 @@ if _os.path.isdir(_db):
     _os.environ.setdefault("MIOPEN_USER_DB_PATH", _db)
 _os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # if a caller turns cudnn.benchmark on: db hit or heuristic, no search
 _os.environ.setdefault("MIOPEN_LOG_LEVEL", "3")
+
+
+def enable_tuned_gemms(path=None):
+    """Turn torch's TunableOp on in LOOK-UP mode with the GEMM table shipped in-tree (pigeon_amd/tunableop/, produced
+    by scripts/tune_gemm.py): Linear layers whose (M, N, K) are in the table run the measured-fastest hipBLASLt /
+    rocBLAS solution, every other shape keeps the library heuristic; nothing is tuned at run time.  Returns True when
+    the table was loaded.  PIGEON_TUNABLEOP=0 disables it."""
+    if _os.environ.get("PIGEON_TUNABLEOP", "1") == "0":
+        return False
+    path = path or _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tunableop", "gfx950_bf16.csv")
+    if not _os.path.exists(path):
+        return False
+    import torch.cuda.tunable as tn
+    if tn.is_enabled():          # the caller manages TunableOp itself
+        return False
+    tn.enable(True)
+    tn.tuning_enable(False)
+    tn.record_untuned_enable(False)
+    return bool(tn.read_file(path))

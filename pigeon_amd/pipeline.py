@@ -53,6 +53,8 @@ class PigeonPixelDecoder:
         self.vae = None if vae is None else vae.to(self.device, self.dtype).eval().requires_grad_(False)
         self.scheduler = scheduler if scheduler is not None else DDIMScheduler()
         self.pixel_decoding = "highres"
+        from . import enable_tuned_gemms
+        self.tuned_gemms = enable_tuned_gemms()
 
     # ---- :897-920 ------------------------------------------------------------------------------
     @torch.no_grad()

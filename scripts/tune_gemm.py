@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Fill a torch TunableOp table for the GEMMs of the hot path (run on the MI355X box).
+
+torch picks hipBLASLt's heuristic solution for every Linear; TunableOp times all hipBLASLt / rocBLAS solutions per
+distinct (transA, transB, M, N, K, dtype) once and records the fastest.  The resulting CSV ships in-tree
+(pigeon_amd/tunableop/) and pigeon_amd enables TunableOp in look-up mode (no tuning at run time); shapes not in the
+table use the heuristic as before.
+
+  python scripts/tune_gemm.py [--batch 16] [--out gpurun_out/tunableop.csv]"""
+import argparse
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["PIGEON_TUNABLEOP"] = "0"   # do not load the shipped table while producing a new one
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--out", default="gpurun_out/tunableop.csv")
+    ap.add_argument("--max-ms", type=int, default=60)
+    args = ap.parse_args()
+    t0 = time.perf_counter()
+
+    def hb():
+        while True:
+            time.sleep(30)
+            print(f"[{time.perf_counter() - t0:6.0f}s] tuning...", flush=True)
+
+    threading.Thread(target=hb, daemon=True).start()
+    from pigeon_amd import ops, synthetic
+    dev = torch.device("cuda", 0)
+    pipe = synthetic.build_random_stack(dev, "bf16", seed=123)
+    import torch.cuda.tunable as tn
+    tn.enable(True)
+    tn.tuning_enable(True)
+    tn.set_max_tuning_duration(args.max_ms)
+    tn.set_max_tuning_iterations(20)
+    tn.set_filename(args.out)
+    B = args.batch
+    h, w = args.height // 8, args.width // 8
+    tokens = [t.to(dev) for t in synthetic.synthetic_tokens(B)]
+    with torch.no_grad():
+        pe, pooled = pipe.generate_image_embeds(tokens)
+        print(f"[{time.perf_counter() - t0:6.0f}s] token decoder tuned", flush=True)
+        ctx = torch.cat([torch.zeros_like(pe), pe])
+        add = torch.cat([torch.zeros_like(pooled), pooled])
+        ids = torch.tensor([[args.width, args.height, 0, 0, args.width, args.height]], dtype=torch.bfloat16,
+                           device=dev).repeat(2 * B, 1)
+        x = ops.cfg_expand_scale(torch.randn(B, 4, h, w, device=dev), torch.bfloat16, 1.0)
+        pipe.unet(x, 961, encoder_hidden_states=ctx, added_cond_kwargs={"text_embeds": add, "time_ids": ids})
+        torch.cuda.synchronize()
+        print(f"[{time.perf_counter() - t0:6.0f}s] unet tuned", flush=True)
+        pipe.decode_latents(torch.randn(1, 4, h, w, device=dev), "uint8")
+        torch.cuda.synchronize()
+    pass  # the table is written when the process exits
+    print(f"[{time.perf_counter() - t0:6.0f}s] {len(tn.get_results())} entries", flush=True)
+    tn.tuning_enable(False)
+    with torch.no_grad():
+        f = lambda: pipe.unet(x, 961, encoder_hidden_states=ctx, added_cond_kwargs={"text_embeds": add, "time_ids": ids})
+        f(); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        print(f"unet fwd with the tuned table: {(time.perf_counter() - t) / 3 * 1e3:.1f} ms", flush=True)
+
+
+if __name__ == "__main__":
+    main()
