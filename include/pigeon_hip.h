@@ -126,6 +126,17 @@ int pgn_cfg_expand_scale(const void* latents, int in_dtype, void* out, int out_d
 int pgn_groupnorm_silu(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma, const void* beta,
                        int affine_dtype, int N, int C, int HW, int G, float eps, int act, void* stream);
 
+/* The same op with a caller-provided workspace, for shapes with few (sample, group) pairs and large groups (the VAE
+ * decoder's GroupNorms at batch 1, diffusers AutoencoderKL.decode reached from lavit_for_pigeon.py:774: 32 pairs of
+ * up to 4 Mi elements; the UNet at batch 1): one workgroup per pair would leave the chip idle, so each group is cut
+ * into slices — per-slice partial statistics go to the workspace, a second launch reduces them in a fixed order and
+ * normalises.  pgn_groupnorm_workspace_bytes returns the bytes this shape needs (0: the one-launch path is used and
+ * `workspace` may be NULL).  workspace: device memory, 8-byte aligned, contents irrelevant on entry. */
+size_t pgn_groupnorm_workspace_bytes(int N, int C, int HW, int G);
+int pgn_groupnorm_silu_ws(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma, const void* beta,
+                          int affine_dtype, int N, int C, int HW, int G, float eps, int act, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-head attention forward, softmax(q k^T * scale + key_bias) v, flash-style on MFMA.
  * Replaces xformers.ops.memory_efficient_attention(q, k, v, attn_bias, scale) as called by diffusers

@@ -273,6 +273,73 @@ __global__ __launch_bounds__(GN_THREADS) void pgn_gn_scalar_kernel(GnArgs a) {
     }
 }
 
+// ---- split path: few (sample, group) pairs, large groups (VAE decode at batch 1: 32 pairs of 4 Mi elements) -------
+// One workgroup per pair would leave most of the chip idle, so a group is cut into S slices, one workgroup each:
+// kernel 1 writes per-slice pivot-shifted (sum, sum of squares) to the workspace, kernel 2 reduces the S partials in a
+// fixed order (deterministic, every workgroup of the group gets identical statistics) and normalises its slice.
+// Two reads + one write, all 16-byte coalesced; the second read follows the first within one launch distance.
+template <int XDT>
+__global__ __launch_bounds__(GN_THREADS) void pgn_gn_split_stats_kernel(GnArgs a, int S, unsigned slice, float2* ws) {
+    __shared__ float red[2 * GN_WAVES];
+    const unsigned pair = blockIdx.x / (unsigned)S, sl = blockIdx.x % (unsigned)S;
+    const size_t base = (size_t)pair * a.group_elems;
+    const unsigned lo = sl * slice, hi = min(lo + slice, a.group_elems);
+    const float pivot = Cvt<XDT>::to_f32(reinterpret_cast<const typename Cvt<XDT>::storage*>(a.x)[base]);
+    float s = 0.f, q = 0.f;
+    for (unsigned v = (lo >> 3) + threadIdx.x; v < (hi >> 3); v += GN_THREADS) {
+        float f[8];
+        ld8<XDT>(a.x, base + ((size_t)v << 3), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = f[j] - pivot;
+            s += d;
+            q += d * d;
+        }
+    }
+    s = block_sum(s, red, 0);
+    q = block_sum(q, red, 1);
+    if (threadIdx.x == 0) ws[blockIdx.x] = make_float2(s, q);
+}
+
+template <int XDT, int YDT, bool UNIFORM_CH>
+__global__ __launch_bounds__(GN_THREADS) void pgn_gn_split_apply_kernel(GnArgs a, int S, unsigned slice,
+                                                                        const float2* ws) {
+    const unsigned pair = blockIdx.x / (unsigned)S, sl = blockIdx.x % (unsigned)S;
+    const size_t base = (size_t)pair * a.group_elems;
+    const int ch0 = (int)(pair % (unsigned)a.G) * a.cpg;
+    const unsigned lo = sl * slice, hi = min(lo + slice, a.group_elems);
+    const float pivot = Cvt<XDT>::to_f32(reinterpret_cast<const typename Cvt<XDT>::storage*>(a.x)[base]);
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < S; ++i) {   // same order in every thread of every workgroup of the pair
+        const float2 p = ws[pair * (unsigned)S + i];
+        s += p.x;
+        q += p.y;
+    }
+    const float inv_n = 1.0f / (float)a.group_elems;
+    const float ms = s * inv_n, mq = q * inv_n;
+    const float mean = pivot + ms;
+    const float rstd = 1.0f / sqrtf(fmaxf(mq - ms * ms, 0.f) + a.eps);
+    for (unsigned v = (lo >> 3) + threadIdx.x; v < (hi >> 3); v += GN_THREADS) {
+        float f[8];
+        ld8<XDT>(a.x, base + ((size_t)v << 3), f);
+        norm_store8<YDT, UNIFORM_CH>(a, base, v << 3, ch0, f, mean, rstd);
+    }
+}
+
+// Slices per group for the split path (0 = do not split).  Split when one workgroup per pair fills less than half
+// of the 256 CUs and the groups are large enough that each slice still streams >= 16 KiB per wavefront.
+static int gn_split_slices(long long pairs, long long group_elems, unsigned* slice_out) {
+    if (pairs >= 128 || group_elems < 131072 || (group_elems & 7) != 0) return 0;
+    long long S = (1024 + pairs - 1) / pairs;
+    if (S > 64) S = 64;
+    long long slice = (group_elems + S - 1) / S;
+    slice = (slice + 8191) / 8192 * 8192;          // whole 1024-thread x 8-element sweeps
+    S = (group_elems + slice - 1) / slice;
+    if (S < 2) return 0;
+    *slice_out = (unsigned)slice;
+    return (int)S;
+}
+
 template <int XDT, int YDT, bool U>
 int launch_vec(const GnArgs& a, int blocks, hipStream_t s) {
     const unsigned nvec = a.group_elems >> 3;
@@ -305,9 +372,16 @@ int launch_dt(const GnArgs& a, int blocks, bool vec_ok, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int pgn_groupnorm_silu(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma,
-                                  const void* beta, int affine_dtype, int N, int C, int HW, int G, float eps,
-                                  int act, void* stream) {
+extern "C" size_t pgn_groupnorm_workspace_bytes(int N, int C, int HW, int G) {
+    if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return 0;
+    unsigned slice;
+    const int S = gn_split_slices((long long)N * G, (long long)(C / G) * HW, &slice);
+    return S > 0 ? (size_t)N * G * S * sizeof(float2) : 0;
+}
+
+extern "C" int pgn_groupnorm_silu_ws(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma,
+                                     const void* beta, int affine_dtype, int N, int C, int HW, int G, float eps,
+                                     int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (x == nullptr || y == nullptr) return PGN_ERR_INVALID;
     if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return PGN_ERR_INVALID;
     if (pgn_dtype_size(x_dtype) == 0 || pgn_dtype_size(y_dtype) == 0) return PGN_ERR_INVALID;
@@ -323,6 +397,26 @@ extern "C" int pgn_groupnorm_silu(const void* x, int x_dtype, void* y, int y_dty
     const int blocks = N * G;
     const bool vec_ok = (ge % 8 == 0) && pgn_aligned(x, 16) && pgn_aligned(y, 16);
     hipStream_t s = (hipStream_t)stream;
+    // split path: only with a caller-provided workspace of the size pgn_groupnorm_workspace_bytes reports
+    unsigned slice = 0;
+    const int S = (workspace != nullptr && vec_ok) ? gn_split_slices(blocks, ge, &slice) : 0;
+    if (S > 0 && x_dtype == y_dtype && (x_dtype == PGN_BF16 || x_dtype == PGN_F16)) {
+        if (workspace_bytes < (size_t)blocks * S * sizeof(float2) || !pgn_aligned(workspace, 8)) return PGN_ERR_INVALID;
+        float2* ws = (float2*)workspace;
+        const dim3 grid((unsigned)(blocks * S)), block(GN_THREADS);
+        const bool u = (HW & 7) == 0;
+        if (x_dtype == PGN_BF16) {
+            hipLaunchKernelGGL((pgn_gn_split_stats_kernel<PGN_BF16>), grid, block, 0, s, a, S, slice, ws);
+            if (u) hipLaunchKernelGGL((pgn_gn_split_apply_kernel<PGN_BF16, PGN_BF16, true>), grid, block, 0, s, a, S, slice, ws);
+            else hipLaunchKernelGGL((pgn_gn_split_apply_kernel<PGN_BF16, PGN_BF16, false>), grid, block, 0, s, a, S, slice, ws);
+        } else {
+            hipLaunchKernelGGL((pgn_gn_split_stats_kernel<PGN_F16>), grid, block, 0, s, a, S, slice, ws);
+            if (u) hipLaunchKernelGGL((pgn_gn_split_apply_kernel<PGN_F16, PGN_F16, true>), grid, block, 0, s, a, S, slice, ws);
+            else hipLaunchKernelGGL((pgn_gn_split_apply_kernel<PGN_F16, PGN_F16, false>), grid, block, 0, s, a, S, slice, ws);
+        }
+        PGN_LAUNCH_CHECK();
+        return PGN_OK;
+    }
     if (x_dtype == PGN_BF16 && y_dtype == PGN_BF16) launch_dt<PGN_BF16, PGN_BF16>(a, blocks, vec_ok, s);
     else if (x_dtype == PGN_F16 && y_dtype == PGN_F16) launch_dt<PGN_F16, PGN_F16>(a, blocks, vec_ok, s);
     else if (x_dtype == PGN_F32 && y_dtype == PGN_F32) launch_dt<PGN_F32, PGN_F32>(a, blocks, vec_ok, s);
@@ -331,4 +425,11 @@ extern "C" int pgn_groupnorm_silu(const void* x, int x_dtype, void* y, int y_dty
     else return PGN_ERR_UNSUPPORTED;
     PGN_LAUNCH_CHECK();
     return PGN_OK;
+}
+
+extern "C" int pgn_groupnorm_silu(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma,
+                                  const void* beta, int affine_dtype, int N, int C, int HW, int G, float eps,
+                                  int act, void* stream) {
+    return pgn_groupnorm_silu_ws(x, x_dtype, y, y_dtype, gamma, beta, affine_dtype, N, C, HW, G, eps, act, nullptr, 0,
+                                 stream);
 }

@@ -232,10 +232,13 @@ def group_norm_silu(x: torch.Tensor, num_groups: int, weight: Optional[torch.Ten
     y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
     work = float(x.numel() * (x.element_size() + y.element_size()))
 
+    ws_bytes = int(lib.pgn_groupnorm_workspace_bytes(N, C, HW, int(num_groups))) if N * C else 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+
     def run():
-        rc = lib.pgn_groupnorm_silu(_ptr(x), _dt(x), _ptr(y), _dt(y), _ptr(weight), _ptr(bias), adt, N, C, HW,
-                                    int(num_groups), float(eps), 1 if silu else 0, _stream())
-        _lib.check(rc, "pgn_groupnorm_silu")
+        rc = lib.pgn_groupnorm_silu_ws(_ptr(x), _dt(x), _ptr(y), _dt(y), _ptr(weight), _ptr(bias), adt, N, C, HW,
+                                       int(num_groups), float(eps), 1 if silu else 0, _ptr(ws), ws_bytes, _stream())
+        _lib.check(rc, "pgn_groupnorm_silu_ws")
 
     _launch("groupnorm_silu" if silu else "groupnorm", work, run)
     return y

@@ -52,6 +52,11 @@ def test_argument_validation_happens_before_any_launch():
     # head_dim other than 64 -> unsupported, 3-channel groups that do not divide -> invalid
     assert lib.pgn_attention_fwd(p16, p16, p16, p16, 1, 1, 1, 1, 1, 40, *([8] * 12), None, 0, 0.1, None) == -2
     assert lib.pgn_groupnorm_silu(p16, 1, p16, 1, None, None, 1, 1, 30, 16, 32, 1e-5, 1, None) == -1
+    # workspace query is host-only arithmetic; a too-small workspace is refused before any launch
+    assert lib.pgn_groupnorm_workspace_bytes(1, 128, 1 << 20, 32) == 32 * 32 * 8
+    assert lib.pgn_groupnorm_workspace_bytes(32, 320, 16384, 32) == 0
+    assert lib.pgn_groupnorm_workspace_bytes(0, 128, 16, 32) == 0
+    assert lib.pgn_groupnorm_silu_ws(p16, 1, p16, 1, None, None, 1, 1, 128, 1 << 20, 32, 1e-6, 1, p16, 64, None) == -1
     # row kernels: nulls -> invalid; D / C not a multiple of 8, fp32 io, C > 4096 -> unsupported
     assert lib.pgn_geglu(None, None, 1, 4, 8, 16, 8, None) == -1
     assert lib.pgn_geglu(p16, p16, 1, 4, 12, 24, 12, None) == -2
