@@ -126,16 +126,21 @@ int pgn_cfg_expand_scale(const void* latents, int in_dtype, void* out, int out_d
 int pgn_groupnorm_silu(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma, const void* beta,
                        int affine_dtype, int N, int C, int HW, int G, float eps, int act, void* stream);
 
-/* The same op with a caller-provided workspace, for shapes with few (sample, group) pairs and large groups (the VAE
- * decoder's GroupNorms at batch 1, diffusers AutoencoderKL.decode reached from lavit_for_pigeon.py:774: 32 pairs of
- * up to 4 Mi elements; the UNet at batch 1): one workgroup per pair would leave the chip idle, so each group is cut
- * into slices — per-slice partial statistics go to the workspace, a second launch reduces them in a fixed order and
- * normalises.  pgn_groupnorm_workspace_bytes returns the bytes this shape needs (0: the one-launch path is used and
- * `workspace` may be NULL).  workspace: device memory, 8-byte aligned, contents irrelevant on entry. */
+/* The same op with two optional extensions (either may be absent):
+ *  add_nc  [N, C] of add_dtype, or NULL: y = act(GN(round_x(x + add_nc[n, c]))).  Replaces the
+ *          `hidden_states = hidden_states + temb[:, :, None, None]` add that precedes norm2 in diffusers 0.27.2
+ *          ResnetBlock2D.forward (a bf16 tensor add, hence the rounding to x's type before the statistics).
+ *  workspace  caller-provided device memory for shapes with few (sample, group) pairs and large groups (the VAE
+ *          decoder's GroupNorms at batch 1, diffusers AutoencoderKL.decode reached from lavit_for_pigeon.py:774: 32
+ *          pairs of up to 4 Mi elements; the UNet at batch 1): one workgroup per pair would leave the chip idle, so
+ *          each group is cut into slices — per-slice partial statistics go to the workspace, a second launch reduces
+ *          them in a fixed order and normalises.  pgn_groupnorm_workspace_bytes returns the bytes the shape needs
+ *          (0: the one-launch path is used and `workspace` may be NULL); 8-byte aligned, contents irrelevant on
+ *          entry.  With add_nc the one-launch path is always used. */
 size_t pgn_groupnorm_workspace_bytes(int N, int C, int HW, int G);
-int pgn_groupnorm_silu_ws(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma, const void* beta,
-                          int affine_dtype, int N, int C, int HW, int G, float eps, int act, void* workspace,
-                          size_t workspace_bytes, void* stream);
+int pgn_groupnorm_silu_ex(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma, const void* beta,
+                          int affine_dtype, const void* add_nc, int add_dtype, int N, int C, int HW, int G, float eps,
+                          int act, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-head attention forward, softmax(q k^T * scale + key_bias) v, flash-style on MFMA.

@@ -121,7 +121,29 @@ struct GnArgs {
     unsigned group_elems;
     float eps;
     int act;
+    const void* addnc;   // optional [N, C] term added (and rounded to the x type) before the statistics, or nullptr
+    int add_dt;
+    int C;
 };
+
+// x + add[n, c] rounded to the x storage type: the bf16 tensor add the reference performs before the norm
+// (diffusers ResnetBlock2D: hidden_states = hidden_states + temb[:, :, None, None]; norm2(hidden_states))
+template <int XDT, bool UNIFORM_CH>
+__device__ __forceinline__ void add_nc8(const GnArgs& a, unsigned pair, unsigned e0, int ch0, float (&f)[8]) {
+    if (a.addnc == nullptr) return;
+    const size_t row = (size_t)(pair / (unsigned)a.G) * (size_t)a.C;
+    if constexpr (UNIFORM_CH) {
+        const float t = load_affine(a.addnc, a.add_dt, (int)row + ch0 + (int)(e0 / (unsigned)a.HW), 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = Cvt<XDT>::to_f32(Cvt<XDT>::from_f32(f[j] + t));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = load_affine(a.addnc, a.add_dt, (int)row + ch0 + (int)((e0 + j) / (unsigned)a.HW), 0.f);
+            f[j] = Cvt<XDT>::to_f32(Cvt<XDT>::from_f32(f[j] + t));
+        }
+    }
+}
 
 // normalise 8 consecutive elements starting at in-group element index e0 and store
 template <int YDT, bool UNIFORM_CH>
@@ -167,6 +189,7 @@ __global__ __launch_bounds__(GN_THREADS) void pgn_gn_resident_kernel(GnArgs a) {
             raw[r] = ld_raw<XDT>(a.x, base + ((size_t)v << 3));
             float f[8];
             raw_to_f32<XDT>(raw[r], f);
+            add_nc8<XDT, UNIFORM_CH>(a, blockIdx.x, v << 3, ch0, f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += f[j];
         }
@@ -181,6 +204,7 @@ __global__ __launch_bounds__(GN_THREADS) void pgn_gn_resident_kernel(GnArgs a) {
             float f[8];
             pin_raw<XDT>(raw[r]);
             raw_to_f32<XDT>(raw[r], f);
+            add_nc8<XDT, UNIFORM_CH>(a, blockIdx.x, v << 3, ch0, f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float d = f[j] - mean;
@@ -197,6 +221,7 @@ __global__ __launch_bounds__(GN_THREADS) void pgn_gn_resident_kernel(GnArgs a) {
             float f[8];
             pin_raw<XDT>(raw[r]);
             raw_to_f32<XDT>(raw[r], f);
+            add_nc8<XDT, UNIFORM_CH>(a, blockIdx.x, v << 3, ch0, f);
             norm_store8<YDT, UNIFORM_CH>(a, base, v << 3, ch0, f, mean, rstd);
         }
     }
@@ -211,11 +236,15 @@ __global__ __launch_bounds__(GN_THREADS) void pgn_gn_stream_kernel(GnArgs a) {
     const int ch0 = (int)(blockIdx.x % (unsigned)a.G) * a.cpg;
     const unsigned tid = threadIdx.x;
 
-    const float pivot = Cvt<XDT>::to_f32(reinterpret_cast<const typename Cvt<XDT>::storage*>(a.x)[base]);
+    float pivot = Cvt<XDT>::to_f32(reinterpret_cast<const typename Cvt<XDT>::storage*>(a.x)[base]);
+    if (a.addnc != nullptr)   // the pivot is the first element of the SUMMED tensor: same statistics as add-then-norm
+        pivot = Cvt<XDT>::to_f32(Cvt<XDT>::from_f32(
+            pivot + load_affine(a.addnc, a.add_dt, (int)((blockIdx.x / (unsigned)a.G) * (unsigned)a.C) + ch0, 0.f)));
     float s = 0.f, q = 0.f;
     for (unsigned v = tid; v < nvec; v += GN_THREADS) {
         float f[8];
         ld8<XDT>(a.x, base + ((size_t)v << 3), f);
+        add_nc8<XDT, UNIFORM_CH>(a, blockIdx.x, v << 3, ch0, f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float d = f[j] - pivot;
@@ -236,6 +265,7 @@ __global__ __launch_bounds__(GN_THREADS) void pgn_gn_stream_kernel(GnArgs a) {
         if (v < nvec) {
             float f[8];
             ld8<XDT>(a.x, base + ((size_t)v << 3), f);
+            add_nc8<XDT, UNIFORM_CH>(a, blockIdx.x, v << 3, ch0, f);
             norm_store8<YDT, UNIFORM_CH>(a, base, v << 3, ch0, f, mean, rstd);
         }
     }
@@ -251,10 +281,18 @@ __global__ __launch_bounds__(GN_THREADS) void pgn_gn_scalar_kernel(GnArgs a) {
     const int ch0 = (int)(blockIdx.x % (unsigned)a.G) * a.cpg;
     const XS* x = reinterpret_cast<const XS*>(a.x) + base;
     YS* y = reinterpret_cast<YS*>(a.y) + base;
-    const float pivot = Cvt<XDT>::to_f32(x[0]);
     float s = 0.f, q = 0.f;
+    const size_t arow = (size_t)(blockIdx.x / (unsigned)a.G) * (size_t)a.C;
+    auto val = [&](unsigned i) {
+        float v = Cvt<XDT>::to_f32(x[i]);
+        if (a.addnc != nullptr)
+            v = Cvt<XDT>::to_f32(Cvt<XDT>::from_f32(
+                v + load_affine(a.addnc, a.add_dt, (int)arow + ch0 + (int)(i / (unsigned)a.HW), 0.f)));
+        return v;
+    };
+    const float pivot = val(0);
     for (unsigned i = threadIdx.x; i < a.group_elems; i += GN_THREADS) {
-        const float d = Cvt<XDT>::to_f32(x[i]) - pivot;
+        const float d = val(i) - pivot;
         s += d;
         q += d * d;
     }
@@ -268,7 +306,7 @@ __global__ __launch_bounds__(GN_THREADS) void pgn_gn_scalar_kernel(GnArgs a) {
         const int c = ch0 + (int)(i / (unsigned)a.HW);
         const float ga = load_affine(a.gamma, a.adt, c, 1.f) * rstd;
         const float be = load_affine(a.beta, a.adt, c, 0.f);
-        float v = (Cvt<XDT>::to_f32(x[i]) - mean) * ga + be;
+        float v = (val(i) - mean) * ga + be;
         y[i] = Cvt<YDT>::from_f32(a.act ? silu_f32(v) : v);
     }
 }
@@ -379,10 +417,12 @@ extern "C" size_t pgn_groupnorm_workspace_bytes(int N, int C, int HW, int G) {
     return S > 0 ? (size_t)N * G * S * sizeof(float2) : 0;
 }
 
-extern "C" int pgn_groupnorm_silu_ws(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma,
-                                     const void* beta, int affine_dtype, int N, int C, int HW, int G, float eps,
-                                     int act, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int pgn_groupnorm_silu_ex(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma,
+                                     const void* beta, int affine_dtype, const void* add_nc, int add_dtype, int N,
+                                     int C, int HW, int G, float eps, int act, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
     if (x == nullptr || y == nullptr) return PGN_ERR_INVALID;
+    if (add_nc != nullptr && pgn_dtype_size(add_dtype) == 0) return PGN_ERR_INVALID;
     if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return PGN_ERR_INVALID;
     if (pgn_dtype_size(x_dtype) == 0 || pgn_dtype_size(y_dtype) == 0) return PGN_ERR_INVALID;
     if ((gamma != nullptr || beta != nullptr) && pgn_dtype_size(affine_dtype) == 0) return PGN_ERR_INVALID;
@@ -393,13 +433,14 @@ extern "C" int pgn_groupnorm_silu_ws(const void* x, int x_dtype, void* y, int y_
     if (ge > 0x7fffffffLL || (long long)N * G > 0x7fffffffLL) return PGN_ERR_UNSUPPORTED;
     GnArgs a;
     a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.adt = affine_dtype; a.cpg = cpg; a.HW = HW; a.G = G;
-    a.group_elems = (unsigned)ge; a.eps = eps; a.act = act;
+    a.group_elems = (unsigned)ge; a.eps = eps; a.act = act; a.addnc = add_nc; a.add_dt = add_dtype; a.C = C;
     const int blocks = N * G;
     const bool vec_ok = (ge % 8 == 0) && pgn_aligned(x, 16) && pgn_aligned(y, 16);
     hipStream_t s = (hipStream_t)stream;
     // split path: only with a caller-provided workspace of the size pgn_groupnorm_workspace_bytes reports
+    // (not combined with add_nc: the shapes that split — VAE decoder, no time embedding — never carry one)
     unsigned slice = 0;
-    const int S = (workspace != nullptr && vec_ok) ? gn_split_slices(blocks, ge, &slice) : 0;
+    const int S = (workspace != nullptr && vec_ok && add_nc == nullptr) ? gn_split_slices(blocks, ge, &slice) : 0;
     if (S > 0 && x_dtype == y_dtype && (x_dtype == PGN_BF16 || x_dtype == PGN_F16)) {
         if (workspace_bytes < (size_t)blocks * S * sizeof(float2) || !pgn_aligned(workspace, 8)) return PGN_ERR_INVALID;
         float2* ws = (float2*)workspace;
@@ -430,6 +471,6 @@ extern "C" int pgn_groupnorm_silu_ws(const void* x, int x_dtype, void* y, int y_
 extern "C" int pgn_groupnorm_silu(const void* x, int x_dtype, void* y, int y_dtype, const void* gamma,
                                   const void* beta, int affine_dtype, int N, int C, int HW, int G, float eps,
                                   int act, void* stream) {
-    return pgn_groupnorm_silu_ws(x, x_dtype, y, y_dtype, gamma, beta, affine_dtype, N, C, HW, G, eps, act, nullptr, 0,
-                                 stream);
+    return pgn_groupnorm_silu_ex(x, x_dtype, y, y_dtype, gamma, beta, affine_dtype, nullptr, 0, N, C, HW, G, eps, act,
+                                 nullptr, 0, stream);
 }

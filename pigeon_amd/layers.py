@@ -23,8 +23,8 @@ class GroupNormAct(nn.Module):
             self.register_parameter("weight", None)
             self.register_parameter("bias", None)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.group_norm_silu(x, self.num_groups, self.weight, self.bias, self.eps, silu=self.act)
+    def forward(self, x: torch.Tensor, add_nc: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return ops.group_norm_silu(x, self.num_groups, self.weight, self.bias, self.eps, silu=self.act, add_nc=add_nc)
 
 
 def timestep_embedding(timesteps: torch.Tensor, dim: int, flip_sin_to_cos: bool, downscale_freq_shift: float,
@@ -66,9 +66,10 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, input_tensor, temb=None):
         h = self.conv1(self.norm1(input_tensor))
+        t = None
         if self.time_emb_proj is not None and temb is not None:
-            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(self.norm2(h))
+            t = self.time_emb_proj(F.silu(temb))   # [N, C]: its broadcast add is fused into norm2's kernel
+        h = self.conv2(self.norm2(h, add_nc=t))
         if self.conv_shortcut is not None:
             input_tensor = self.conv_shortcut(input_tensor)
         out = input_tensor + h

@@ -212,10 +212,12 @@ def cfg_expand_scale(latents: torch.Tensor, out_dtype: torch.dtype, divisor: flo
 
 # ------------------------------------------------------------------------------------------------
 def group_norm_silu(x: torch.Tensor, num_groups: int, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
-                    eps: float = 1e-5, silu: bool = True, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """GroupNorm (+SiLU) on an NCHW-contiguous tensor [N, C, *spatial]; fp32 statistics and arithmetic."""
+                    eps: float = 1e-5, silu: bool = True, out_dtype: Optional[torch.dtype] = None,
+                    add_nc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm (+SiLU) on an NCHW-contiguous tensor [N, C, *spatial]; fp32 statistics and arithmetic.
+    add_nc [N, C]: normalise x + add_nc[:, :, None, None] (rounded to x.dtype first, as the tensor add it replaces)."""
     lib = _lib.load()
-    _dev(x, weight, bias)
+    _dev(x, weight, bias, add_nc)
     if x.dim() < 2:
         raise ValueError("group_norm_silu expects [N, C, ...]")
     x = x.contiguous()
@@ -232,13 +234,20 @@ def group_norm_silu(x: torch.Tensor, num_groups: int, weight: Optional[torch.Ten
     y = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
     work = float(x.numel() * (x.element_size() + y.element_size()))
 
-    ws_bytes = int(lib.pgn_groupnorm_workspace_bytes(N, C, HW, int(num_groups))) if N * C else 0
+    add_dt = PGN_F32
+    if add_nc is not None:
+        if add_nc.shape != (N, C):
+            raise ValueError("add_nc must be [N, C]")
+        add_nc = add_nc.contiguous()
+        add_dt = _dt(add_nc)
+    ws_bytes = int(lib.pgn_groupnorm_workspace_bytes(N, C, HW, int(num_groups))) if N * C and add_nc is None else 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
 
     def run():
-        rc = lib.pgn_groupnorm_silu_ws(_ptr(x), _dt(x), _ptr(y), _dt(y), _ptr(weight), _ptr(bias), adt, N, C, HW,
-                                       int(num_groups), float(eps), 1 if silu else 0, _ptr(ws), ws_bytes, _stream())
-        _lib.check(rc, "pgn_groupnorm_silu_ws")
+        rc = lib.pgn_groupnorm_silu_ex(_ptr(x), _dt(x), _ptr(y), _dt(y), _ptr(weight), _ptr(bias), adt, _ptr(add_nc),
+                                       add_dt, N, C, HW, int(num_groups), float(eps), 1 if silu else 0, _ptr(ws),
+                                       ws_bytes, _stream())
+        _lib.check(rc, "pgn_groupnorm_silu_ex")
 
     _launch("groupnorm_silu" if silu else "groupnorm", work, run)
     return y

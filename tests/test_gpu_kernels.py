@@ -193,6 +193,26 @@ def test_groupnorm_silu_matches_oracle(ops, case):
         assert (got != want).float().mean().item() < 0.02  # only rare 1-ulp rounding flips
 
 
+@pytest.mark.parametrize("shape", [(4, 320, 128, 128), (2, 640, 64, 64), (2, 1280, 38, 26), (2, 64, 5, 3)],
+                         ids=["stream", "resident", "straddle", "scalar"])
+def test_groupnorm_fused_channel_add_equals_add_then_norm(ops, shape):
+    # ResnetBlock2D: norm2(h + temb[:, :, None, None]) — the kernel adds, rounds to bf16 and normalises in one pass;
+    # bit-identical to the kernel applied to the separately added (bf16) tensor, and within tolerance of the oracle
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(N, C, H, W, generator=g).to(torch.bfloat16)
+    t = (torch.randn(N, C, generator=g) * 0.5).to(torch.bfloat16)
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(torch.bfloat16)
+    b = (0.2 * torch.randn(C, generator=g)).to(torch.bfloat16)
+    summed = x + t[:, :, None, None]                       # torch bf16 add (CPU): fp32 add, one rounding
+    want = ops_ref.group_norm_silu_ref(summed, 32, w, b, 1e-5, True)
+    fused = ops.group_norm_silu(x.to(DEV), 32, w.to(DEV), b.to(DEV), 1e-5, True, add_nc=t.to(DEV))
+    two_step = ops.group_norm_silu(summed.to(DEV), 32, w.to(DEV), b.to(DEV), 1e-5, True)
+    assert torch.equal(fused, two_step)
+    err = (fused.cpu().float() - want.float()).abs()
+    assert bool((err <= 2.0 ** -7 * want.float().abs() + 2.0 ** -12).all())
+
+
 def test_groupnorm_split_path_is_selected_and_deterministic(ops):
     from pigeon_amd import _lib
     lib = _lib.load()
