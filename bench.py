@@ -187,9 +187,11 @@ def main():
         one_step()
     fence()
     state["phase"] = "timed steps"
-    timer.enabled = not args.no_kernel_timing
+    # HIP-event brackets around every C-ABI launch cost ~1 % of a step (25 k event pairs), so they are recorded during
+    # the LAST timed step only: still inside the timed region, on the launch stream, at 1/K of the cost
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        timer.enabled = (not args.no_kernel_timing) and i == args.steps - 1
         one_step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -208,10 +210,10 @@ def main():
             continue
         if kind == "attention":
             kernels[kind] = {"launches": n, "avg_us": secs / n * 1e6, "TFLOP/s": work / secs / 1e12,
-                             "share_of_step": secs / elapsed}
+                             "share_of_step": secs / (elapsed / args.steps)}
         else:
             kernels[kind] = {"launches": n, "avg_us": secs / n * 1e6, "GB/s": work / secs / 1e9,
-                             "share_of_step": secs / elapsed}
+                             "share_of_step": secs / (elapsed / args.steps)}
     roofline = None
     if "attention" in agg:
         n, work, secs = agg["attention"]

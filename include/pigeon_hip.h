@@ -185,6 +185,15 @@ int pgn_geglu(const void* h, void* y, int dtype, int64_t M, int D, int64_t ld_h,
 int pgn_add_layernorm(const void* x, const void* residual, void* sum_out, void* y, const void* gamma,
                       const void* beta, int dtype, int affine_dtype, int64_t M, int C, float eps, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * VAE output -> displayable bytes in one pass: y[n, h, w, c] = uint8(rint(clamp(float(x[n, c, h, w]) / 2 + 0.5, 0, 1)
+ * * 255)), rint = round half to even.  Replaces lavit_for_pigeon.py:780-782 (`image.float()`, `/ 2 + 0.5`,
+ * `.clamp(0, 1)`, `.permute(0, 2, 3, 1)`) and numpy_to_pil :929 (`(images * 255).round().astype("uint8")`), which the
+ * reference runs as fp32 tensor ops plus a 4x larger device->host copy.  Each fp32 operation is rounded separately, so
+ * the bytes are identical to the reference's.  x: [N, C, H, W] of x_dtype, C <= 4; y: [N, H, W, C] uint8.
+ */
+int pgn_image_to_uint8(const void* x, int x_dtype, void* y, int N, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ SIGNATURES = {
                                    _vp]),
     "pgn_geglu": (_i, [_vp, _vp, _i, _i64, _i, _i64, _i64, _vp]),
     "pgn_add_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _vp]),
+    "pgn_image_to_uint8": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "pgn_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [_i64] * 12 + [_vp, _i64, _f, _vp]),
 }
 

@@ -136,6 +136,36 @@ __global__ __launch_bounds__(EW_THREADS) void pgn_add_layernorm_kernel(
     }
 }
 
+
+// ---- VAE output -> uint8 NHWC ---------------------------------------------------------------------
+// lavit_for_pigeon.py:780-782 + numpy_to_pil :929: image.float() / 2 + 0.5, clamp(0, 1), NCHW -> NHWC,
+// (x * 255).round() (half to even), uint8.  Every fp32 operation is rounded separately (this file is built with
+// -ffp-contract=off), so the bytes equal the reference's.
+template <int DT, int PX>
+__global__ __launch_bounds__(EW_THREADS) void pgn_image_u8_kernel(const void* __restrict__ x, unsigned char* __restrict__ y,
+                                                                  int C, long long HW, long long total_px) {
+    typedef typename Cvt<DT>::storage XS;
+    const XS* xp = reinterpret_cast<const XS*>(x);
+    const long long step = (long long)gridDim.x * EW_THREADS * PX;
+    for (long long p0 = ((long long)blockIdx.x * EW_THREADS + threadIdx.x) * PX; p0 < total_px; p0 += step) {
+        const long long n = p0 / HW, hw = p0 - n * HW;     // PX consecutive pixels never straddle images (HW % PX == 0)
+        unsigned char out[PX * 4];
+        for (int c = 0; c < C; ++c) {
+            const XS* src = xp + (n * C + c) * HW + hw;
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                float v = Cvt<DT>::to_f32(src[i]);
+                v = v / 2.0f + 0.5f;
+                v = fminf(fmaxf(v, 0.0f), 1.0f);
+                if (v != v) v = 0.0f;   // NaN: numpy's cast of NaN to uint8 is undefined; write 0
+                out[i * C + c] = (unsigned char)__builtin_rintf(v * 255.0f);
+            }
+        }
+        unsigned char* dst = y + p0 * C;
+        for (int i = 0; i < PX * C; ++i) dst[i] = out[i];
+    }
+}
+
 }  // namespace
 
 extern "C" int pgn_geglu(const void* h, void* y, int dtype, int64_t M, int D, int64_t ld_h, int64_t ld_y,
@@ -199,6 +229,30 @@ extern "C" int pgn_add_layernorm(const void* x, const void* residual, void* sum_
     }
 #undef PGN_LN_R
 #undef PGN_LN_LAUNCH
+    PGN_LAUNCH_CHECK();
+    return PGN_OK;
+}
+
+extern "C" int pgn_image_to_uint8(const void* x, int x_dtype, void* y, int N, int C, int H, int W, void* stream) {
+    if (x == nullptr || y == nullptr) return PGN_ERR_INVALID;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || pgn_dtype_size(x_dtype) == 0) return PGN_ERR_INVALID;
+    if (C > 4) return PGN_ERR_UNSUPPORTED;
+    const long long HW = (long long)H * W, total = HW * N;
+    hipStream_t s = (hipStream_t)stream;
+    const bool quad = (HW % 4) == 0;
+    const long long work = quad ? total / 4 : total;
+    long long blocks = (work + EW_THREADS - 1) / EW_THREADS;
+    if (blocks > 256LL * 32) blocks = 256LL * 32;
+    const dim3 grid((unsigned)blocks), block(EW_THREADS);
+#define PGN_U8(DT)                                                                                          \
+    do {                                                                                                    \
+        if (quad) hipLaunchKernelGGL((pgn_image_u8_kernel<DT, 4>), grid, block, 0, s, x, (unsigned char*)y, C, HW, total); \
+        else hipLaunchKernelGGL((pgn_image_u8_kernel<DT, 1>), grid, block, 0, s, x, (unsigned char*)y, C, HW, total);      \
+    } while (0)
+    if (x_dtype == PGN_BF16) PGN_U8(PGN_BF16);
+    else if (x_dtype == PGN_F16) PGN_U8(PGN_F16);
+    else PGN_U8(PGN_F32);
+#undef PGN_U8
     PGN_LAUNCH_CHECK();
     return PGN_OK;
 }

@@ -307,6 +307,25 @@ def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: Op
     return (s if residual is not None else x), y
 
 
+def image_to_uint8(x: torch.Tensor) -> torch.Tensor:
+    """[N, C, H, W] decoder output in [-1, 1] -> [N, H, W, C] uint8, the reference's post-processing
+    (lavit_for_pigeon.py:780-782,929) in one launch, byte-identical."""
+    lib = _lib.load()
+    _dev(x)
+    if x.dim() != 4:
+        raise ValueError("image_to_uint8 expects [N, C, H, W]")
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    y = torch.empty(N, H, W, C, dtype=torch.uint8, device=x.device)
+
+    def run():
+        rc = lib.pgn_image_to_uint8(_ptr(x), _dt(x), _ptr(y), N, C, H, W, _stream())
+        _lib.check(rc, "pgn_image_to_uint8")
+
+    _launch("image_u8", float(x.numel() * (x.element_size() + 1)), run)
+    return y
+
+
 # ------------------------------------------------------------------------------------------------
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
               key_bias: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -138,11 +138,12 @@ class PigeonPixelDecoder:
         outs = []
         for i in range(0, z.shape[0], max(1, chunk)):
             image = self.vae.decode(z[i:i + chunk]).sample
-            image = (image.float() / 2 + 0.5).clamp(0, 1)
             if output_type != "np":
-                # uint8 on the device: 4x fewer bytes over PCIe than the reference's fp32 copy; same rounding as
-                # numpy_to_pil ((x * 255).round(), half to even)
-                image = (image * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+                # uint8 NHWC on the device in one launch: 4x fewer bytes over PCIe than the reference's fp32 copy;
+                # same arithmetic and rounding as :780-782 + numpy_to_pil ((x * 255).round(), half to even)
+                image = ops.image_to_uint8(image)
+            else:
+                image = (image.float() / 2 + 0.5).clamp(0, 1)
             outs.append(image)
         image = torch.cat(outs, dim=0)
         if output_type == "np":

@@ -33,6 +33,8 @@ with torch.no_grad():
     f = lambda: pipe.unet(x, 961, encoder_hidden_states=ctx, added_cond_kwargs={"text_embeds": add, "time_ids": ids}).sample
     timed("unet fwd (first, MIOpen find)", f)
     timed("unet fwd", f, 3)
+    torch.cuda.synchronize(); t = time.perf_counter(); f(); t_enq = time.perf_counter() - t; torch.cuda.synchronize()
+    log(f"unet fwd host enqueue time (no sync): {t_enq*1e3:.1f} ms")
     if os.environ.get("PROFILE"):
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CUDA]) as prof:

@@ -410,3 +410,18 @@ def test_row_kernels_full_size_properties(ops):
     assert ops.geglu(h2).abs().max().item() == 0
     hidden, gate = h.chunk(2, dim=-1)
     assert torch.equal(out, hidden * torch.nn.functional.gelu(gate))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 3, 64, 48), (1, 3, 7, 5), (1, 1, 16, 16), (3, 4, 9, 4)])
+def test_image_to_uint8_bit_exact(ops, dtype, shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g) * 0.8).to(dtype)
+    # exact ties of the final rounding and the clamp edges
+    x.view(-1)[:6] = torch.tensor([-1.0, 1.0, -3.0, 3.0, 1.0 / 255 - 1, 0.0]).to(dtype)
+    # lavit_for_pigeon.py:780-782 + numpy_to_pil :929
+    ref = (x.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+    want = (ref * 255).round().astype("uint8")
+    got = ops.image_to_uint8(x.to(DEV)).cpu().numpy()
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert (got == want).all()
