@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cross-kv-cache", action="store_true", help="reuse cross-attention K/V across denoising steps")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal of the multi-rank control flow on a one-GPU box: every rank uses cuda:0 (gloo only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -134,11 +137,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.single_device:
+        if args.dist_backend == "nccl" and world > 1:
+            raise SystemExit("--single-device shares one GPU between ranks: RCCL refuses that, use --dist-backend gloo")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     t_start = time.perf_counter()
     state = {"phase": "build"}
@@ -196,7 +206,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    tt = torch.tensor([elapsed], device=device if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
@@ -240,7 +250,7 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: SER-30K-style sticker batch 16 per GPU, 1024x1024, "
+            "config": {"workload": f"configs[1]: SER-30K-style sticker batch {args.batch} per GPU, {args.width}x{args.height}, "
                                    f"{args.denoise_steps} DDIM steps with CFG {args.guidance}, bf16, synthetic tokens, "
                                    "random-init SDXL-shaped decoder (UNet 2.57B + token decoder 414M + VAE); "
                                    "end to end incl. VAE decode and uint8 copy to host",

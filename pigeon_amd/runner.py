@@ -38,12 +38,17 @@ def all_gather_results(latents: torch.Tensor, scores: Optional[torch.Tensor], co
         return latents, scores
     m = max(counts)
 
+    host_staged = dist.get_backend(group) == "gloo"   # gloo collectives run on host memory
+
     def gather(t):
+        dev = t.device
+        if host_staged:
+            t = t.cpu()
         pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         pad[: t.shape[0]] = t
         out = torch.empty((world * m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
-        return torch.cat([out[r * m: r * m + counts[r]] for r in range(world)], dim=0)
+        return torch.cat([out[r * m: r * m + counts[r]] for r in range(world)], dim=0).to(dev)
 
     return gather(latents), (None if scores is None else gather(scores))
 
