@@ -21,9 +21,10 @@
 
 namespace {
 
-constexpr int ATT_D = 64;
 constexpr int ATT_BN = 64;       // keys per tile
-constexpr int ATT_TILE_ELEMS = ATT_BN * ATT_D;  // 4096 x 16-bit = 8 KiB
+// Head dims: the kernel is instantiated for a PADDED head dim DP of 64 or 128; a head dim D < DP (D % 8 == 0: the
+// token decoder's 88, SD-1.5's 40 / 80) is zero-filled up to DP on the way into registers / LDS (zero q and k columns
+// add nothing to the scores, zero v columns are never stored), so callers pass their tensors as they are.
 // a workgroup = NWAVES wave64, 32 query rows each: NWAVES = 8 (256 rows, 2 waves per SIMD) for long key sequences,
 // NWAVES = 4 (128 rows, several workgroups per CU) when the key loop is short and prologue latency dominates
 
@@ -38,7 +39,7 @@ struct AttnArgs {
     const unsigned short* v;
     unsigned short* o;
     const float* bias;
-    int H, Nq, Nk, nqt;
+    int H, Nq, Nk, nqt, D;
     long long q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh, bias_sb;
     float c;  // scale * log2(e)
 };
@@ -65,17 +66,30 @@ __device__ __forceinline__ float xhalf_sum(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// LDS byte offsets of 16-byte chunk `ch` (0..7) of key row `row` (0..63)
-__device__ __forceinline__ int k_lds_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+// LDS byte offsets of 16-byte chunk `ch` (0..DP/8-1) of key row `row` (0..63).  K rows are XOR-swizzled so that the 16
+// lanes ds_read_b128 serves together (16 different rows, same logical chunk) hit 16 different 16-byte columns of the
+// 256-byte bank line: two 128-byte rows per line at DP = 64, one 256-byte row per line at DP = 128.
+template <int DP>
+__device__ __forceinline__ int k_lds_off(int row, int ch) {
+    if constexpr (DP == 64) return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+    else return row * 256 + ((ch ^ (row & 15)) << 4);
+}
+// V: 8-key x 32-dim sub-tiles of 512 bytes (what ds_read_b64_tr_b16 transposes), DP/32 of them per 8-key group
+template <int DP>
 __device__ __forceinline__ int v_lds_off(int row, int ch) {
-    return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * (ch & 3);
+    return (16 * DP) * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * (ch & 3);
 }
 
-template <int DT, bool HAS_BIAS, int NWAVES, int MINW>
-__global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_d64_kernel(AttnArgs a) {
+template <int DT, bool HAS_BIAS, int NWAVES, int MINW, int DP, bool PAD>
+__global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArgs a) {
     constexpr int ATT_THREADS = NWAVES * 64;
     constexpr int ATT_BM = NWAVES * 32;
-    constexpr int NSTAGE = 512 / ATT_THREADS;  // (row, chunk) pairs of each 64 x 8-chunk tile per thread
+    constexpr int ATT_TILE_ELEMS = ATT_BN * DP;         // 8 KiB (DP 64) / 16 KiB (DP 128) of 16-bit elements
+    constexpr int NCH = DP / 8;                          // 16-byte chunks per key row
+    constexpr int SROWS = ATT_THREADS / NCH;             // key rows staged per pass
+    constexpr int NSTAGE = ATT_BN / SROWS;               // (row, chunk) pairs of each tile per thread
+    constexpr int NKS = DP / 16;                         // MFMA k-steps of the score product
+    constexpr int NOD = DP / 32;                         // 32-dim blocks of the output accumulator
     // [buf][K|V][8 KiB] + [buf][64 floats of key bias]; one object so the base stays 16-byte aligned
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * ATT_TILE_ELEMS * 2 + 2 * ATT_BN * 4];
     float* bias_lds = reinterpret_cast<float*>(smem + 2 * 2 * ATT_TILE_ELEMS * 2);
@@ -94,32 +108,36 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_d64_kernel(Att
     const int qrow = qt * ATT_BM + wid * 32 + l31;
     const int qrow_c = qrow < a.Nq ? qrow : a.Nq - 1;
     const unsigned short* qp = a.q + b * a.q_sb + (long long)qrow_c * a.q_sn + h * a.q_sh + 8 * hh;
-    u16x8_t qf[4];
+    const u16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    u16x8_t qf[NKS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const u16x8_t*>(qp + 16 * s);
+    for (int s = 0; s < NKS; ++s) {
+        if (!PAD || 16 * s + 8 * hh < a.D) qf[s] = *reinterpret_cast<const u16x8_t*>(qp + 16 * s);
+        else qf[s] = zero8;
+    }
 
     // ---- staging assignment: thread -> (key row, 16-byte chunk) of the K and V tiles
-    const int srow = tid >> 3, sch = tid & 7;   // + i * (ATT_THREADS / 8) rows for the i-th staged chunk
+    const int srow = tid / NCH, sch = tid % NCH;   // + i * SROWS rows for the i-th staged chunk
+    const bool sch_ok = !PAD || sch * 8 < a.D;     // chunks past the real head dim are staged as zeros
     const unsigned short* kp = a.k + b * a.k_sb + h * a.k_sh + sch * 8;
     const unsigned short* vp = a.v + b * a.v_sb + h * a.v_sh + sch * 8;
     int k_woff[NSTAGE], v_woff[NSTAGE];
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i) {
-        k_woff[i] = k_lds_off(srow + i * (ATT_THREADS / 8), sch);
-        v_woff[i] = v_lds_off(srow + i * (ATT_THREADS / 8), sch);
+        k_woff[i] = k_lds_off<DP>(srow + i * SROWS, sch);
+        v_woff[i] = v_lds_off<DP>(srow + i * SROWS, sch);
     }
     const float* bp = HAS_BIAS ? a.bias + b * a.bias_sb : nullptr;
 
     const int nt = (a.Nk + ATT_BN - 1) / ATT_BN;
-    const u16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     u16x8_t kreg[NSTAGE], vreg[NSTAGE];
     float breg = 0.f;
     auto stage_load = [&](int t) {
 #pragma unroll
         for (int i = 0; i < NSTAGE; ++i) {
-            const int key = t * ATT_BN + srow + i * (ATT_THREADS / 8);
-            if (key < a.Nk) {
+            const int key = t * ATT_BN + srow + i * SROWS;
+            if (key < a.Nk && sch_ok) {
                 kreg[i] = *reinterpret_cast<const u16x8_t*>(kp + (long long)key * a.k_sn);
                 vreg[i] = *reinterpret_cast<const u16x8_t*>(vp + (long long)key * a.v_sn);
             } else {
@@ -148,19 +166,19 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_d64_kernel(Att
 
     // ---- per-lane read offsets
     // K (A operand of S^T): row = kb*32 + l31, chunk = 2 s + hh
-    int k_roff[2][4];
+    int k_roff[2][NKS];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) k_roff[kb][s] = k_lds_off(kb * 32 + l31, 2 * s + hh);
+        for (int s = 0; s < NKS; ++s) k_roff[kb][s] = k_lds_off<DP>(kb * 32 + l31, 2 * s + hh);
     // V (A operand of O^T = V^T P^T) through ds_read_b64_tr_b16: lane i of a 16-lane group supplies
     // row (i>>2), columns 4*(i&3).. of the group's 4-key x 16-dim block
     const int i16 = lane & 15, g16 = (lane >> 4) & 1;
     const int v_lane_off = 64 * (i16 >> 2) + 32 * g16 + 8 * (i16 & 3);
 
-    f32x16_t oacc[2];
+    f32x16_t oacc[NOD];
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < NOD; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     float m_run = -1.0e30f;  // running max (raw score units without bias, exp2 units with bias)
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_d64_kernel(Att
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NKS; ++s) {
                 const u16x8_t kf = *reinterpret_cast<const u16x8_t*>(kt + k_roff[kb][s]);
                 sacc[kb] = mfma32<DT>(kf, qf[s], sacc[kb]);
             }
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_d64_kernel(Att
             l_run *= alpha;
             const f32x2_t alpha2 = {alpha, alpha};
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+            for (int d = 0; d < NOD; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     f32x2_t o2 = {oacc[d][r], oacc[d][r + 1]};
@@ -255,17 +273,17 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_d64_kernel(Att
 
         // ---- O^T += V^T P^T : A operand element j of lane half hh is key 16 s2 + 8 (j>>2) + 4 hh + (j&3)
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < NOD; ++d) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int key0 = kb * 32 + 16 * s2 + 4 * hh;  // multiple of 4; +8 for the upper 4 elements
-                    const int off0 = 1024 * (key0 >> 3) + 64 * (key0 & 7) + 512 * d + v_lane_off;
+                    const int off0 = (16 * DP) * (key0 >> 3) + 64 * (key0 & 7) + 512 * d + v_lane_off;
                     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4_t*)(vt + off0));
                     const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t*)(vt + off0 + 1024));
+                        (__attribute__((address_space(3))) s16x4_t*)(vt + off0 + 16 * DP));
                     u16x8_t vf;
                     vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
                     vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
@@ -289,13 +307,14 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_d64_kernel(Att
     if (qrow < a.Nq) {
         unsigned short* op = a.o + b * a.o_sb + (long long)qrow * a.o_sn + h * a.o_sh;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+        for (int d = 0; d < NOD; ++d)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 u16x4_t w;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = Cvt<DT>::from_f32(oacc[d][4 * g4 + j] * inv);
-                *reinterpret_cast<u16x4_t*>(op + d * 32 + 8 * g4 + 4 * hh) = w;
+                if (!PAD || d * 32 + 8 * g4 + 4 * hh < a.D)   // D % 4 == 0: a 4-dim group is inside or outside
+                    *reinterpret_cast<u16x4_t*>(op + d * 32 + 8 * g4 + 4 * hh) = w;
             }
     }
 }
@@ -315,7 +334,7 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     if (q == nullptr || k == nullptr || v == nullptr || out == nullptr) return PGN_ERR_INVALID;
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || D <= 0) return PGN_ERR_INVALID;
     if (dtype != PGN_BF16 && dtype != PGN_F16) return PGN_ERR_UNSUPPORTED;
-    if (D != ATT_D) return PGN_ERR_UNSUPPORTED;
+    if (D > 128 || (D & 7) != 0) return PGN_ERR_UNSUPPORTED;   // head dims 8..128 in steps of 8 (16-byte row chunks)
     // 16-byte vector loads of q/k/v rows, 8-byte stores of out rows
     const int64_t st[12] = {q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh};
     for (int i = 0; i < 12; ++i)
@@ -327,7 +346,7 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     // SDXL shape (scripts/bench_kernels.py): 4 waves beat the 8-wave 256-row geometry by 4 % (self, N 4096) to
     // 30 % (cross, Nk 256); the 8-wave form stays reachable through pgn_attention_tuning for A/B runs.
     int nw = 4;
-    if (g_attn_variant == 1) nw = 8;
+    if (g_attn_variant == 1 && D == 64) nw = 8;
     if (g_attn_variant == 2) nw = 4;
     const int bm = nw * 32;
     const long long nqt = (Nq + bm - 1) / bm;
@@ -337,16 +356,20 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     AttnArgs a;
     a.q = (const unsigned short*)q; a.k = (const unsigned short*)k; a.v = (const unsigned short*)v;
     a.o = (unsigned short*)out; a.bias = key_bias;
-    a.H = H; a.Nq = Nq; a.Nk = Nk; a.nqt = (int)nqt;
+    a.H = H; a.Nq = Nq; a.Nk = Nk; a.nqt = (int)nqt; a.D = D;
     a.q_sb = q_sb; a.q_sn = q_sn; a.q_sh = q_sh; a.k_sb = k_sb; a.k_sn = k_sn; a.k_sh = k_sh;
     a.v_sb = v_sb; a.v_sn = v_sn; a.v_sh = v_sh; a.o_sb = o_sb; a.o_sn = o_sn; a.o_sh = o_sh; a.bias_sb = bias_sb;
     a.c = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), block(nw * 64);
-#define PGN_ATT_LAUNCH(DT, BIAS)                                                                          \
-    do {                                                                                                  \
-        if (nw == 8) hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<DT, BIAS, 8, 2>), grid, block, 0, s, a);   \
-        else hipLaunchKernelGGL((pgn_attn_fwd_d64_kernel<DT, BIAS, 4, 2>), grid, block, 0, s, a);           \
+#define PGN_ATT_LAUNCH(DT, BIAS)                                                                                  \
+    do {                                                                                                          \
+        if (D == 64) {                                                                                            \
+            if (nw == 8) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 8, 2, 64, false>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 64, false>), grid, block, 0, s, a);        \
+        } else if (D < 64) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 64, true>), grid, block, 0, s, a); \
+        else if (D == 128) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 128, false>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 128, true>), grid, block, 0, s, a);           \
     } while (0)
     if (dtype == PGN_BF16) {
         if (key_bias != nullptr) PGN_ATT_LAUNCH(PGN_BF16, true);

@@ -8,7 +8,10 @@ Runs once per batch, outside the denoising loop.  MI355X-first differences (resu
 order; the reference's per-sample Python pad loop :315-317 and its `.tolist()` / `.max().item()` host syncs are gone):
   * `forward_padded` consumes the fixed-shape `[B, 256, 32]` + mask output of the fused gather kernel;
     padded key columns receive the same additive -10000 bias as the reference's mask, i.e. exactly zero weight;
-  * attention goes through fused scaled-dot-product kernels instead of materialised [B, 16, 256, L] score tensors;
+  * on the GPU the 88-wide attention heads (self, masked cross, pool) run in the HIP MFMA kernel (pgn_attention_fwd,
+    head dims up to 128) reading the fused qkv / key / value projections in place, and the fp32-statistics LayerNorms
+    in the HIP row kernel (pgn_add_layernorm) — no materialised [B, 16, 256, L] score tensors.  Called on CPU tensors
+    (host-logic tests against the reference's golden vectors) the same module evaluates with torch ops;
   * the attention pool evaluates only the one query row whose output is used (`x[0]`, :177).
 `forward(x, token_num)` keeps the reference signature (packed rows + counts).
 """
@@ -19,11 +22,31 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
+
+
+def _on_hip(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)
+
+
+def _attention(q, k, v, heads: int, scale: float, key_bias: Optional[torch.Tensor] = None):
+    """softmax(q k^T * scale + key_bias) v on [B, N, heads*D] tensors (last dim contiguous, any row stride)."""
+    if _on_hip(q):
+        return ops.attention(q, k, v, heads, scale, key_bias)
+    B, Nq, C = q.shape
+    D = C // heads
+    split = lambda t: t.reshape(B, -1, heads, D).transpose(1, 2)
+    mask = None if key_bias is None else key_bias[:, None, None, :].to(q.dtype)
+    o = F.scaled_dot_product_attention(split(q), split(k), split(v), attn_mask=mask, scale=scale)
+    return o.transpose(1, 2).reshape(B, Nq, C)
+
 
 class _LayerNormFp32(nn.LayerNorm):
     """fp32 statistics regardless of the activation dtype (modeling_decoder.py:11-17)."""
 
     def forward(self, x):
+        if _on_hip(x) and self.weight is not None and x.shape[-1] % 8 == 0:
+            return ops.add_layer_norm(x, None, self.weight, self.bias, self.eps)[1]
         w = None if self.weight is None else self.weight.float()
         b = None if self.bias is None else self.bias.float()
         return F.layer_norm(x.float(), self.normalized_shape, w, b, self.eps).to(x.dtype)
@@ -49,10 +72,9 @@ class _SelfAttention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x).view(B, N, 3, self.num_heads, C // self.num_heads)
-        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
-        o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
-        return self.proj(o.transpose(1, 2).reshape(B, N, C))
+        qkv = self.qkv(x)                                   # [B, N, 3C] = [q | k | v], heads contiguous inside each
+        o = _attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], self.num_heads, self.scale)
+        return self.proj(o)
 
 
 class _CrossAttention(nn.Module):
@@ -66,13 +88,9 @@ class _CrossAttention(nn.Module):
         self.proj = nn.Linear(dim, dim, bias=qkv_bias)
 
     def forward(self, x, codebook_embeds, bias):
-        B, L, C = codebook_embeds.shape
-        H, D = self.num_heads, C // self.num_heads
-        q = self.query(x).view(B, -1, H, D).transpose(1, 2)
-        k = self.key(codebook_embeds).view(B, L, H, D).transpose(1, 2)
-        v = self.value(codebook_embeds).view(B, L, H, D).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=bias, scale=self.scale)
-        return self.proj(o.transpose(1, 2).reshape(B, -1, C))
+        o = _attention(self.query(x), self.key(codebook_embeds), self.value(codebook_embeds), self.num_heads,
+                       self.scale, bias)
+        return self.proj(o)
 
 
 class _Block(nn.Module):
@@ -105,11 +123,9 @@ class _AttentionPool(nn.Module):
         B, N, C = x.shape
         H, D = self.num_heads, C // self.num_heads
         x = torch.cat([x.mean(dim=1, keepdim=True), x], dim=1) + self.positional_embedding[None].to(x.dtype)
-        q = self.q_proj(x[:, :1]).view(B, 1, H, D).transpose(1, 2)      # only the pooled query is returned
-        k = self.k_proj(x).view(B, N + 1, H, D).transpose(1, 2)
-        v = self.v_proj(x).view(B, N + 1, H, D).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v)
-        return self.c_proj(o.transpose(1, 2).reshape(B, C))
+        q = self.q_proj(x[:, :1])                                       # only the pooled query is returned
+        o = _attention(q, self.k_proj(x), self.v_proj(x), H, D ** -0.5)
+        return self.c_proj(o.reshape(B, C))
 
 
 class HighresVQDecoder(nn.Module):
@@ -146,7 +162,7 @@ class HighresVQDecoder(nn.Module):
         m = mask.to(dtype)
         x = self.in_proj(x_pad.to(dtype)) * m[..., None]          # padding rows are zeros, not the bias (:312-316)
         x = x + self.pos_embed[:, :L]
-        bias = ((1.0 - m) * -10000.0)[:, None, None, :]          # :100-101
+        bias = (1.0 - m.float()) * -10000.0                      # :100-101, one additive value per key: [B, L]
         q = self.query_embed.expand(B, -1, -1)
         for blk in self.blocks:
             q = blk(q, x, bias)

@@ -425,3 +425,37 @@ def test_image_to_uint8_bit_exact(ops, dtype, shape):
     got = ops.image_to_uint8(x.to(DEV)).cpu().numpy()
     assert got.shape == want.shape and got.dtype == want.dtype
     assert (got == want).all()
+
+
+# (B, heads, Nq, Nk, head_dim, bias): head dims beyond the UNet's 64
+ATTN_D_CASES = [
+    (2, 16, 256, 256, 88, False),    # token decoder self-attention (modeling_decoder.py:44-71): 16 heads x 88
+    (2, 16, 256, 90, 88, True),      # token decoder cross-attention with the -10000 pad mask (:74-109)
+    (2, 4, 300, 300, 128, False),
+    (1, 2, 4096, 4096, 128, False),
+    (2, 8, 1024, 77, 40, False),     # SD-1.5 level 1 (lowres variant, lavit_for_pigeon.py:822-895)
+    (2, 8, 256, 77, 80, True),       # SD-1.5 level 2 with encoder_attention_mask
+    (1, 3, 65, 130, 8, False),
+    (1, 2, 130, 65, 120, True),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_D_CASES, ids=[f"B{c[0]}H{c[1]}q{c[2]}k{c[3]}d{c[4]}{'b' if c[5] else ''}" for c in ATTN_D_CASES])
+def test_attention_other_head_dims(ops, case):
+    B, H, Nq, Nk, D, has_bias = case
+    g = torch.Generator().manual_seed(Nq + Nk + D)
+    C = H * D
+    q = (torch.randn(B, Nq, C, generator=g) * 1.2).to(torch.bfloat16)
+    k = (torch.randn(B, Nk, C, generator=g) * 1.2).to(torch.bfloat16)
+    v = torch.randn(B, Nk, C, generator=g).to(torch.bfloat16)
+    bias = None
+    if has_bias:
+        keep = torch.randint(1, Nk + 1, (B,), generator=g)
+        bias = (1.0 - (torch.arange(Nk)[None, :] < keep[:, None]).float()) * -10000.0
+    want = ops_ref.attention_ref(q, k, v, H, None, bias).float()
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H, None, None if bias is None else bias.to(DEV)).cpu().float()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < 2.0 ** -7 * max(1.0, want.abs().max().item())
+    with pytest.raises(NotImplementedError):
+        ops.attention(torch.zeros(1, 8, 512, device=DEV).bfloat16(), torch.zeros(1, 8, 512, device=DEV).bfloat16(),
+                      torch.zeros(1, 8, 512, device=DEV).bfloat16(), 1)   # the VAE's 512-wide head is not covered

@@ -241,4 +241,8 @@ def test_generate_image_argument_errors_and_generator_path(stack):
     # same seed -> same noise; MIOpen / hipBLASLt may pick different algorithms on a first call, so compare closely
     # rather than bitwise
     assert a.dtype == torch.float32 and a.shape == (1, 4, 16, 16)
-    assert _rel(a, b)[1] < 0.02
+    assert _rel(a, b)[1] < 0.06      # bf16 noise floor of two evaluations (stream-K GEMMs are not run-to-run bitwise)
+    gen.manual_seed(124)
+    c = pipe.generate_image(image_tokens=toks, width=128, height=128, num_inference_steps=2, generator=gen,
+                            output_type="latent")[0]
+    assert _rel(a, c)[1] > 0.5       # a different seed is a different image
