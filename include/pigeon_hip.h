@@ -48,7 +48,8 @@ typedef enum { PGN_PRED_EPSILON = 0, PGN_PRED_SAMPLE = 1, PGN_PRED_V = 2 } pgn_p
 int pgn_version(void);
 const char* pgn_error_string(int code);
 
-/* Workspace query kept for ABI stability; every op below currently needs 0 bytes. */
+/* Per-op workspace query kept for ABI stability: 0 for every op (the one shape-dependent workspace, GroupNorm's
+ * split path, has its own query: pgn_groupnorm_workspace_bytes). */
 typedef enum { PGN_OP_GATHER = 0, PGN_OP_CFG_STEP = 1, PGN_OP_GROUPNORM = 2, PGN_OP_ATTENTION = 3 } pgn_op;
 size_t pgn_workspace_bytes(int op);
 
