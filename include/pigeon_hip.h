@@ -143,6 +143,18 @@ int pgn_groupnorm_silu_ex(const void* x, int x_dtype, void* y, int y_dtype, cons
                           int affine_dtype, const void* add_nc, int add_dtype, int N, int C, int HW, int G, float eps,
                           int act, void* workspace, size_t workspace_bytes, void* stream);
 
+/* GroupNorm (+SiLU) for CHANNELS-LAST activations: x, y are [N, HW, C] (torch memory_format channels_last of the
+ * logical [N, C, H, W]), the layout the MIOpen / CK convolution kernels compute in — keeping the UNet / VAE in it
+ * removes the NCHW<->NHWC transposes MIOpen otherwise runs around every convolution and makes the [B, HW, C] view of
+ * diffusers Transformer2DModel free.  Same reference call sites and arithmetic as pgn_groupnorm_silu_ex (add_nc as
+ * there).  Three launches (per-chunk per-channel partial statistics -> per-group mean / rstd -> apply), deterministic;
+ * the workspace (pgn_groupnorm_nhwc_workspace_bytes, 8-byte aligned, contents irrelevant) is mandatory.
+ * bf16 / f16, C % 8 == 0, C <= 8192, C / G <= 128.  Algorithmic bytes as pgn_groupnorm_silu. */
+size_t pgn_groupnorm_nhwc_workspace_bytes(int N, int C, int HW, int G);
+int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const void* gamma, const void* beta, int affine_dtype,
+                            const void* add_nc, int add_dtype, int N, int C, int HW, int G, float eps, int act,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-head attention forward, softmax(q k^T * scale + key_bias) v, flash-style on MFMA.
  * Replaces xformers.ops.memory_efficient_attention(q, k, v, attn_bias, scale) as called by diffusers

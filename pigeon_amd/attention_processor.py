@@ -36,7 +36,7 @@ class HipAttnProcessor:
         input_ndim = hidden_states.ndim
         if input_ndim == 4:
             b, c, h, w = hidden_states.shape
-            hidden_states = hidden_states.view(b, c, h * w).transpose(1, 2)
+            hidden_states = hidden_states.reshape(b, c, h * w).transpose(1, 2)
         if getattr(attn, "group_norm", None) is not None:
             hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
 
@@ -72,6 +72,8 @@ class HipAttnProcessor:
 
         if input_ndim == 4:
             hidden_states = hidden_states.transpose(-1, -2).reshape(b, c, h, w)
+            if residual.is_contiguous(memory_format=torch.channels_last) and not residual.is_contiguous():
+                hidden_states = hidden_states.contiguous(memory_format=torch.channels_last)
         if attn.residual_connection:
             hidden_states = hidden_states + residual
         if attn.rescale_output_factor != 1.0:
@@ -89,7 +91,7 @@ class TorchSdpaAttnProcessor:
         input_ndim = hidden_states.ndim
         if input_ndim == 4:
             b, c, h, w = hidden_states.shape
-            hidden_states = hidden_states.view(b, c, h * w).transpose(1, 2)
+            hidden_states = hidden_states.reshape(b, c, h * w).transpose(1, 2)
         if getattr(attn, "group_norm", None) is not None:
             hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
         context = hidden_states if encoder_hidden_states is None else encoder_hidden_states
@@ -106,6 +108,8 @@ class TorchSdpaAttnProcessor:
         hidden_states = attn.to_out[1](attn.to_out[0](o.transpose(1, 2).reshape(B, Nq, C)))
         if input_ndim == 4:
             hidden_states = hidden_states.transpose(-1, -2).reshape(b, c, h, w)
+            if residual.is_contiguous(memory_format=torch.channels_last) and not residual.is_contiguous():
+                hidden_states = hidden_states.contiguous(memory_format=torch.channels_last)
         if attn.residual_connection:
             hidden_states = hidden_states + residual
         if attn.rescale_output_factor != 1.0:

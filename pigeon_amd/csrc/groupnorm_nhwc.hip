@@ -1,0 +1,248 @@
+// GroupNorm (+SiLU), channels-last: x[n, p, c] with p = h*W + w (see include/pigeon_hip.h: pgn_groupnorm_silu_nhwc).
+// Same op as groupnorm_silu.hip for activations kept in the layout the MIOpen / CK convolution kernels compute in
+// (torch memory_format channels_last): no NCHW<->NHWC transposes around every convolution, and the [B, HW, C] view the
+// transformer blocks want is free.
+//
+// A (sample, group) is now a strided set (C/G channels out of every C), so a workgroup streams whole rows instead:
+//   thread -> (row lane r, 16-byte channel chunk cc); a wavefront reads 1 KiB of consecutive bytes per access.
+//   kernel 1 (stats)    per (sample, row chunk): per-channel pivot-shifted sum / sum of squares, reduced over the row
+//                       lanes through LDS, written to the workspace  [N][S][C] float2
+//   kernel 2 (finalize) per (sample, group): fixed-order reduction over chunks and channels -> mean, rstd  [N][G] float2
+//                       (per-CHANNEL pivots p_c = x[n, 0, c]: sum_x (x-mu)^2 = sum_c q_c + 2 (p_c-mu) s_c + HW (p_c-mu)^2)
+//   kernel 3 (apply)    same mapping as kernel 1: (x - mean) * rstd * gamma + beta, SiLU, store
+// Two reads + one write of the tensor (the second read follows the first by one launch: L2 / Infinity Cache for the
+// smaller tensors), deterministic, no atomics.
+#include "pgn_common.h"
+
+namespace {
+
+constexpr int NH_MAX_THREADS = 1024;
+
+struct NhArgs {
+    const void* x;
+    void* y;
+    const void* gamma;
+    const void* beta;
+    const void* addnc;
+    int adt, add_dt;
+    int C, HW, G, cpg;
+    int C8;          // 16-byte chunks per row
+    int R;           // row lanes per workgroup
+    int S;           // row chunks per sample
+    int rows;        // rows per chunk
+    float eps;
+    int act;
+    float2* part;    // [N][S][C]
+    float2* stats;   // [N][G]
+};
+
+__device__ __forceinline__ float nh_param(const void* p, int dt, size_t i, float dflt) {
+    if (p == nullptr) return dflt;
+    if (dt == PGN_F32) return reinterpret_cast<const float*>(p)[i];
+    const unsigned short h = reinterpret_cast<const unsigned short*>(p)[i];
+    return dt == PGN_BF16 ? Cvt<PGN_BF16>::to_f32(h) : Cvt<PGN_F16>::to_f32(h);
+}
+
+template <int DT>
+__device__ __forceinline__ void nh_load8(const NhArgs& a, size_t elem, const float (&t)[8], bool has_add, float (&f)[8]) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(a.x) + elem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = Cvt<DT>::to_f32(v[j]);
+    if (has_add) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[j] + t[j]));   // the reference's bf16 add
+    }
+}
+
+__device__ __forceinline__ float nh_silu(float v) {
+    const float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int DT>
+__global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArgs a) {
+    extern __shared__ float2 sh[];   // [R][C]
+    const int n = blockIdx.x / a.S, sc = blockIdx.x % a.S;
+    const int t = threadIdx.x;
+    const int r = t / a.C8, cc = t - r * a.C8;
+    const bool active = r < a.R;
+    const size_t img = (size_t)n * a.HW * a.C;
+    const bool has_add = a.addnc != nullptr;
+    float tadd[8], piv[8], s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { tadd[j] = 0.f; piv[j] = 0.f; s[j] = 0.f; q[j] = 0.f; }
+    if (active) {
+        if (has_add) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tadd[j] = nh_param(a.addnc, a.add_dt, (size_t)n * a.C + cc * 8 + j, 0.f);
+        }
+        nh_load8<DT>(a, img + (size_t)cc * 8, tadd, has_add, piv);   // row 0 of the sample: one pivot per channel
+        const int row1 = min(a.HW, (sc + 1) * a.rows);
+        for (int row = sc * a.rows + r; row < row1; row += a.R) {
+            float f[8];
+            nh_load8<DT>(a, img + (size_t)row * a.C + cc * 8, tadd, has_add, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = f[j] - piv[j];
+                s[j] += d;
+                q[j] += d * d;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[(size_t)r * a.C + cc * 8 + j] = make_float2(s[j], q[j]);
+    }
+    __syncthreads();
+    for (int c = t; c < a.C; c += blockDim.x) {
+        float ss = 0.f, qq = 0.f;
+        for (int rr = 0; rr < a.R; ++rr) {
+            const float2 v = sh[(size_t)rr * a.C + c];
+            ss += v.x;
+            qq += v.y;
+        }
+        a.part[((size_t)n * a.S + sc) * a.C + c] = make_float2(ss, qq);
+    }
+}
+
+// one wavefront per (sample, group)
+template <int DT>
+__global__ __launch_bounds__(64) void pgn_gn_nhwc_finalize_kernel(NhArgs a) {
+    const int n = blockIdx.x / a.G, g = blockIdx.x % a.G;
+    const int lane = threadIdx.x;
+    const float hw = (float)a.HW;
+    // pass 1: per-channel totals (channels lane, lane + 64 of the group), then the group mean
+    float S0 = 0.f, Q0 = 0.f, p0 = 0.f, S1 = 0.f, Q1 = 0.f, p1 = 0.f;
+    const int c0 = g * a.cpg + lane, c1 = c0 + 64;
+    const bool v0 = lane < a.cpg, v1 = lane + 64 < a.cpg;
+    auto pivot = [&](int c) {
+        float p = Cvt<DT>::to_f32(reinterpret_cast<const unsigned short*>(a.x)[(size_t)n * a.HW * a.C + c]);
+        if (a.addnc != nullptr)
+            p = Cvt<DT>::to_f32(Cvt<DT>::from_f32(p + nh_param(a.addnc, a.add_dt, (size_t)n * a.C + c, 0.f)));
+        return p;
+    };
+    if (v0) {
+        p0 = pivot(c0);
+        for (int sc = 0; sc < a.S; ++sc) {
+            const float2 v = a.part[((size_t)n * a.S + sc) * a.C + c0];
+            S0 += v.x;
+            Q0 += v.y;
+        }
+    }
+    if (v1) {
+        p1 = pivot(c1);
+        for (int sc = 0; sc < a.S; ++sc) {
+            const float2 v = a.part[((size_t)n * a.S + sc) * a.C + c1];
+            S1 += v.x;
+            Q1 += v.y;
+        }
+    }
+    float m = (v0 ? p0 + S0 / hw : 0.f) + (v1 ? p1 + S1 / hw : 0.f);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off);
+    const float mean = m / (float)a.cpg;
+    float var = 0.f;
+    if (v0) { const float d = p0 - mean; var += Q0 + 2.f * d * S0 + hw * d * d; }
+    if (v1) { const float d = p1 - mean; var += Q1 + 2.f * d * S1 + hw * d * d; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off);
+    var = fmaxf(var / ((float)a.cpg * hw), 0.f);
+    if (lane == 0) a.stats[(size_t)n * a.G + g] = make_float2(mean, 1.0f / sqrtf(var + a.eps));
+}
+
+template <int DT>
+__global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArgs a) {
+    const int n = blockIdx.x / a.S, sc = blockIdx.x % a.S;
+    const int t = threadIdx.x;
+    const int r = t / a.C8, cc = t - r * a.C8;
+    if (r >= a.R) return;
+    const size_t img = (size_t)n * a.HW * a.C;
+    const bool has_add = a.addnc != nullptr;
+    float tadd[8], mean[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cc * 8 + j;
+        tadd[j] = has_add ? nh_param(a.addnc, a.add_dt, (size_t)n * a.C + c, 0.f) : 0.f;
+        const float2 st = a.stats[(size_t)n * a.G + c / a.cpg];
+        mean[j] = st.x;
+        ga[j] = nh_param(a.gamma, a.adt, c, 1.f) * st.y;
+        be[j] = nh_param(a.beta, a.adt, c, 0.f);
+    }
+    const int row1 = min(a.HW, (sc + 1) * a.rows);
+    unsigned short* yp = reinterpret_cast<unsigned short*>(a.y);
+    for (int row = sc * a.rows + r; row < row1; row += a.R) {
+        const size_t e = img + (size_t)row * a.C + cc * 8;
+        float f[8];
+        nh_load8<DT>(a, e, tadd, has_add, f);
+        u16x8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = (f[j] - mean[j]) * ga[j] + be[j];
+            o[j] = Cvt<DT>::from_f32(a.act ? nh_silu(v) : v);
+        }
+        *reinterpret_cast<u16x8_t*>(yp + e) = o;
+    }
+}
+
+// geometry shared by the workspace query and the launch
+static bool nh_geometry(int N, int C, int HW, int G, NhArgs* a) {
+    if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return false;
+    if ((C & 7) != 0 || C / 8 > NH_MAX_THREADS || C / G > 128) return false;
+    a->C = C; a->HW = HW; a->G = G; a->cpg = C / G; a->C8 = C / 8;
+    int R = NH_MAX_THREADS / a->C8;
+    if (R > HW) R = HW;
+    if (R > 64) R = 64;
+    a->R = R;
+    long long target = 2048 / N;                 // ~8 workgroups per CU over the whole launch
+    if (target < 1) target = 1;
+    if (target > 64) target = 64;
+    long long rows = (HW + target - 1) / target;
+    if (rows < 8LL * R) rows = 8LL * R;         // at least 8 rows per lane: amortise the LDS reduction
+    if (rows > HW) rows = HW;
+    a->rows = (int)rows;
+    a->S = (int)((HW + rows - 1) / rows);
+    return true;
+}
+
+}  // namespace
+
+extern "C" size_t pgn_groupnorm_nhwc_workspace_bytes(int N, int C, int HW, int G) {
+    NhArgs a;
+    if (!nh_geometry(N, C, HW, G, &a)) return 0;
+    return ((size_t)N * a.S * C + (size_t)N * G) * sizeof(float2);
+}
+
+extern "C" int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const void* gamma, const void* beta,
+                                       int affine_dtype, const void* add_nc, int add_dtype, int N, int C, int HW, int G,
+                                       float eps, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    if (x == nullptr || y == nullptr || workspace == nullptr) return PGN_ERR_INVALID;
+    if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return PGN_ERR_INVALID;
+    if ((gamma == nullptr) != (beta == nullptr)) return PGN_ERR_INVALID;
+    if (gamma != nullptr && pgn_dtype_size(affine_dtype) == 0) return PGN_ERR_INVALID;
+    if (add_nc != nullptr && pgn_dtype_size(add_dtype) == 0) return PGN_ERR_INVALID;
+    if ((act != 0 && act != 1) || !(eps >= 0.f)) return PGN_ERR_INVALID;
+    if (dtype != PGN_BF16 && dtype != PGN_F16) return PGN_ERR_UNSUPPORTED;
+    NhArgs a;
+    if (!nh_geometry(N, C, HW, G, &a)) return PGN_ERR_UNSUPPORTED;
+    if ((long long)N * a.S > 0x7fffffffLL || (long long)N * HW * C > 0x7fffffffffffLL) return PGN_ERR_UNSUPPORTED;
+    if (!pgn_aligned(x, 16) || !pgn_aligned(y, 16) || !pgn_aligned(workspace, 8)) return PGN_ERR_INVALID;
+    const size_t need = ((size_t)N * a.S * C + (size_t)N * G) * sizeof(float2);
+    if (workspace_bytes < need) return PGN_ERR_INVALID;
+    a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.addnc = add_nc; a.adt = affine_dtype; a.add_dt = add_dtype;
+    a.eps = eps; a.act = act;
+    a.part = (float2*)workspace;
+    a.stats = a.part + (size_t)N * a.S * C;
+    hipStream_t s = (hipStream_t)stream;
+    const int threads = ((a.R * a.C8 + 63) / 64) * 64;
+    const size_t lds = (size_t)a.R * C * sizeof(float2);
+    const dim3 grid((unsigned)(N * a.S)), block(threads);
+    if (dtype == PGN_BF16) {
+        hipLaunchKernelGGL((pgn_gn_nhwc_stats_kernel<PGN_BF16>), grid, block, lds, s, a);
+        hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<PGN_BF16>), dim3(N * G), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<PGN_BF16>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((pgn_gn_nhwc_stats_kernel<PGN_F16>), grid, block, lds, s, a);
+        hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<PGN_F16>), dim3(N * G), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<PGN_F16>), grid, block, 0, s, a);
+    }
+    PGN_LAUNCH_CHECK();
+    return PGN_OK;
+}

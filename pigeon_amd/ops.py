@@ -220,6 +220,10 @@ def group_norm_silu(x: torch.Tensor, num_groups: int, weight: Optional[torch.Ten
     _dev(x, weight, bias, add_nc)
     if x.dim() < 2:
         raise ValueError("group_norm_silu expects [N, C, ...]")
+    if (x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16) and not x.is_contiguous()
+            and x.is_contiguous(memory_format=torch.channels_last) and out_dtype in (None, x.dtype)
+            and x.shape[1] % 8 == 0 and x.shape[1] // num_groups <= 128):
+        return _group_norm_silu_nhwc(x, num_groups, weight, bias, eps, silu, add_nc)
     x = x.contiguous()
     N, C = x.shape[0], x.shape[1]
     HW = x.numel() // (N * C) if N * C else 0
@@ -250,6 +254,39 @@ def group_norm_silu(x: torch.Tensor, num_groups: int, weight: Optional[torch.Ten
         _lib.check(rc, "pgn_groupnorm_silu_ex")
 
     _launch("groupnorm_silu" if silu else "groupnorm", work, run)
+    return y
+
+
+def _group_norm_silu_nhwc(x, num_groups, weight, bias, eps, silu, add_nc):
+    """channels_last input -> channels_last output through pgn_groupnorm_silu_nhwc (no layout change, no copy)."""
+    lib = _lib.load()
+    N, C, H, W = x.shape
+    HW = H * W
+    if (weight is None) != (bias is None):
+        raise ValueError("weight and bias must both be given or both be None")
+    adt = PGN_F32
+    if weight is not None:
+        if weight.dtype != bias.dtype or weight.numel() != C or bias.numel() != C:
+            raise ValueError("affine parameters must be [C] and share a dtype")
+        weight, bias = weight.contiguous(), bias.contiguous()
+        adt = _dt(weight)
+    add_dt = PGN_F32
+    if add_nc is not None:
+        if add_nc.shape != (N, C):
+            raise ValueError("add_nc must be [N, C]")
+        add_nc = add_nc.contiguous()
+        add_dt = _dt(add_nc)
+    y = torch.empty_like(x)     # preserves the channels_last strides
+    ws_bytes = int(lib.pgn_groupnorm_nhwc_workspace_bytes(N, C, HW, int(num_groups)))
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=x.device)
+
+    def run():
+        rc = lib.pgn_groupnorm_silu_nhwc(_ptr(x), _ptr(y), _dt(x), _ptr(weight), _ptr(bias), adt, _ptr(add_nc), add_dt,
+                                         N, C, HW, int(num_groups), float(eps), 1 if silu else 0, _ptr(ws), ws_bytes,
+                                         _stream())
+        _lib.check(rc, "pgn_groupnorm_silu_nhwc")
+
+    _launch("groupnorm_silu" if silu else "groupnorm", float(2 * x.numel() * x.element_size()), run)
     return y
 
 

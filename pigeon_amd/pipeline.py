@@ -42,7 +42,7 @@ class PigeonPixelDecoder:
     """Owns the frozen decoder stack (codebook, token decoder, UNet, scheduler, VAE) on one GPU."""
 
     def __init__(self, codebook: torch.Tensor, tokenizer_decoder, unet, vae, scheduler=None,
-                 model_dtype: str = "bf16", device: Union[str, torch.device] = "cuda"):
+                 model_dtype: str = "bf16", device: Union[str, torch.device] = "cuda", channels_last: bool = True):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("PigeonPixelDecoder runs on an MI355X (device 'cuda:N'); there is no CPU path")
@@ -55,6 +55,10 @@ class PigeonPixelDecoder:
         self.pixel_decoding = "highres"
         from . import enable_tuned_gemms
         self.tuned_gemms = enable_tuned_gemms()
+        if channels_last:
+            for m in (self.unet, self.vae):
+                if m is not None and hasattr(m, "enable_channels_last"):
+                    m.enable_channels_last(True)
 
     # ---- :897-920 ------------------------------------------------------------------------------
     @torch.no_grad()

@@ -137,11 +137,18 @@ class Transformer2DModel(nn.Module):
             hidden_states, pending = block(hidden_states, encoder_hidden_states, encoder_attention_mask,
                                            attention_mask, pending=pending, defer_add=True)
         hidden_states = pending + hidden_states
+        # channels_last activations: [B, HW, C] IS the memory of the [B, C, H, W] tensor, so both reshapes are views;
+        # NCHW activations need the transposing copy diffusers makes
+        cl = residual.is_contiguous(memory_format=torch.channels_last) and not residual.is_contiguous()
         if self.use_linear_projection:
             hidden_states = self.proj_out(hidden_states)
-            hidden_states = hidden_states.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous()
+            hidden_states = hidden_states.reshape(b, h, w, c).permute(0, 3, 1, 2)
+            if not cl:
+                hidden_states = hidden_states.contiguous()
         else:
-            hidden_states = hidden_states.reshape(b, h, w, -1).permute(0, 3, 1, 2).contiguous()
+            hidden_states = hidden_states.reshape(b, h, w, -1).permute(0, 3, 1, 2)
+            if not cl:
+                hidden_states = hidden_states.contiguous()
             hidden_states = self.proj_out(hidden_states)
         return hidden_states + residual
 
@@ -300,6 +307,14 @@ class UNet2DConditionModel(nn.Module):
         """What lavit_for_pigeon.py:202 calls; on MI355X the memory-efficient kernel is the HIP one."""
         self.set_attn_processor(HipAttnProcessor())
 
+    def enable_channels_last(self, enabled: bool = True):
+        """Keep activations and convolution weights in torch's channels_last memory format: the layout the MIOpen / CK
+        convolution kernels compute in (no NCHW<->NHWC transposes around each convolution), served by the channels-last
+        GroupNorm kernel; the [B, HW, C] reshapes of the transformer blocks become views.  Results are unchanged."""
+        self.channels_last = enabled
+        self.to(memory_format=torch.channels_last if enabled else torch.contiguous_format)
+        return self
+
     def enable_cross_kv_cache(self, enabled: bool = True):
         for m in self.modules():
             if isinstance(m, Attention) and isinstance(m.processor, HipAttnProcessor):
@@ -376,7 +391,10 @@ class UNet2DConditionModel(nn.Module):
             sample = 2 * sample - 1.0
 
         # 2. down
-        sample = self.conv_in(sample.to(dtype))
+        sample = sample.to(dtype)
+        if getattr(self, "channels_last", False):
+            sample = sample.contiguous(memory_format=torch.channels_last)
+        sample = self.conv_in(sample)
         res_samples = (sample,)
         for block in self.down_blocks:
             sample, outs = block(sample, emb, encoder_hidden_states, encoder_attention_mask)

@@ -130,6 +130,14 @@ class AutoencoderKL(nn.Module):
             model = model.to(torch_dtype)
         return model.eval()
 
+    def enable_channels_last(self, enabled: bool = True):
+        """See UNet2DConditionModel.enable_channels_last."""
+        self.channels_last = enabled
+        self.to(memory_format=torch.channels_last if enabled else torch.contiguous_format)
+        return self
+
     def decode(self, z: torch.Tensor, return_dict: bool = True):
+        if getattr(self, "channels_last", False):
+            z = z.contiguous(memory_format=torch.channels_last)
         dec = self.decoder(self.post_quant_conv(z))
         return DecoderOutput(sample=dec) if return_dict else (dec,)

@@ -37,6 +37,9 @@ for C, HW in ((320, 16384), (640, 16384), (960, 16384), (640, 4096), (1280, 4096
     x = torch.randn(Bp, C, HW, device=dev).bfloat16(); w = torch.randn(C, device=dev).bfloat16(); b = torch.randn(C, device=dev).bfloat16()
     t = timeit(lambda: ops.group_norm_silu(x, 32, w, b, 1e-5, True))
     res.append((f"gn_silu_{C}x{HW}", t * 1e6, x.numel() * 4 / t / 1e9, "GB/s"))
+    xc = x.view(Bp, C, int(HW ** 0.5), -1).contiguous(memory_format=torch.channels_last)
+    t = timeit(lambda: ops.group_norm_silu(xc, 32, w, b, 1e-5, True))
+    res.append((f"gn_silu_nhwc_{C}x{HW}", t * 1e6, x.numel() * 4 / t / 1e9, "GB/s"))
     if os.environ.get("TORCHGN"):
         gn = torch.nn.GroupNorm(32, C).to(dev).bfloat16()
         t2 = timeit(lambda: torch.nn.functional.silu(gn(x)), iters=5, warm=2)

@@ -61,6 +61,11 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.pgn_groupnorm_silu_ex(p16, 1, p16, 1, None, None, 1, p16, 7, 1, 128, 64, 32, 1e-6, 1, None, 0, None) == -1
     assert lib.pgn_image_to_uint8(None, 1, None, 1, 3, 8, 8, None) == -1
     assert lib.pgn_image_to_uint8(p16, 1, p16, 1, 5, 8, 8, None) == -2
+    assert lib.pgn_groupnorm_nhwc_workspace_bytes(32, 320, 16384, 32) > 0
+    assert lib.pgn_groupnorm_nhwc_workspace_bytes(1, 36, 16, 4) == 0                       # C % 8 != 0: not covered
+    assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 1, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 1, None, 0, None) == -1
+    assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 1, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 1, p16, 8, None) == -1
+    assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 0, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 1, p16, 1 << 20, None) == -2
     # row kernels: nulls -> invalid; D / C not a multiple of 8, fp32 io, C > 4096 -> unsupported
     assert lib.pgn_geglu(None, None, 1, 4, 8, 16, 8, None) == -1
     assert lib.pgn_geglu(p16, p16, 1, 4, 12, 24, 12, None) == -2

@@ -459,3 +459,36 @@ def test_attention_other_head_dims(ops, case):
     with pytest.raises(NotImplementedError):
         ops.attention(torch.zeros(1, 8, 512, device=DEV).bfloat16(), torch.zeros(1, 8, 512, device=DEV).bfloat16(),
                       torch.zeros(1, 8, 512, device=DEV).bfloat16(), 1)   # the VAE's 512-wide head is not covered
+
+
+NHWC_CASES = [
+    (2, 320, 128, 128, True, True), (2, 640, 64, 64, True, False), (2, 1280, 32, 32, True, True),
+    (2, 2560, 32, 32, True, False), (1, 960, 128, 128, True, False), (2, 640, 64, 64, False, False),
+    (2, 640, 76, 52, True, True), (2, 1920, 38, 26, True, False), (1, 128, 256, 256, True, False),
+    (3, 64, 5, 3, True, True), (2, 512, 16, 16, False, False), (1, 256, 1, 1, True, False),
+]
+
+
+@pytest.mark.parametrize("case", NHWC_CASES, ids=[f"{c[1]}x{c[2]}x{c[3]}{'s' if c[4] else ''}{'a' if c[5] else ''}" for c in NHWC_CASES])
+def test_groupnorm_channels_last_matches_oracle(ops, case):
+    N, C, H, W, silu, with_add = case
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * (0.5 + torch.rand(1, C, 1, 1, generator=g) * 2)
+         + torch.randn(1, C, 1, 1, generator=g)).to(torch.bfloat16)
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(torch.bfloat16)
+    b = (0.2 * torch.randn(C, generator=g)).to(torch.bfloat16)
+    t = (torch.randn(N, C, generator=g) * 0.5).to(torch.bfloat16) if with_add else None
+    eps = 1e-5 if silu else 1e-6
+    xin = x if t is None else x + t[:, :, None, None]
+    want = ops_ref.group_norm_silu_ref(xin, 32, w, b, eps, silu)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    got = ops.group_norm_silu(xd, 32, w.to(DEV), b.to(DEV), eps, silu, add_nc=None if t is None else t.to(DEV))
+    assert got.shape == x.shape and got.dtype == x.dtype
+    if H * W > 1:
+        assert got.is_contiguous(memory_format=torch.channels_last)
+    err = (got.cpu().float() - want.float()).abs()
+    ulp = 2.0 ** -7
+    assert bool((err <= ulp * want.float().abs() + 4 * ulp * 2.0 ** -7 + 1e-6).all()), err.max().item()
+    assert (got.cpu() != want).float().mean().item() < 0.02
+    again = ops.group_norm_silu(xd, 32, w.to(DEV), b.to(DEV), eps, silu, add_nc=None if t is None else t.to(DEV))
+    assert torch.equal(got, again)     # no atomics: run-to-run bit-identical
