@@ -218,7 +218,7 @@ def main():
     for kind, (n, work, secs) in agg.items():
         if secs <= 0:
             continue
-        if kind == "attention":
+        if kind.startswith("attention"):
             kernels[kind] = {"launches": n, "avg_us": secs / n * 1e6, "TFLOP/s": work / secs / 1e12,
                              "share_of_step": secs / (elapsed / args.steps)}
         else:
@@ -228,8 +228,9 @@ def main():
     if "attention" in agg:
         n, work, secs = agg["attention"]
         ach = work / secs / 1e12
-        traffic, src = pmc_traffic("pgn_attn_fwd_d64_kernel")
-        roofline = {"kernel": "pgn_attn_fwd_d64_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+        # the UNet's instantiation (bf16, no key bias, 4 waves, head dim 64); other head dims are timed as their own kind
+        traffic, src = pmc_traffic("pgn_attn_fwd_kernel<1, false, 4, 2, 64, false>")
+        roofline = {"kernel": "pgn_attn_fwd_kernel<bf16, head_dim 64>", "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": src, "launches": n, "avg_launch_us": secs / n * 1e6,
                     "flop_per_launch": work / n}

@@ -78,16 +78,27 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArg
         }
         nh_load8<DT>(a, img + (size_t)cc * 8, tadd, has_add, piv);   // row 0 of the sample: one pivot per channel
         const int row1 = min(a.HW, (sc + 1) * a.rows);
-        for (int row = sc * a.rows + r; row < row1; row += a.R) {
-            float f[8];
-            nh_load8<DT>(a, img + (size_t)row * a.C + cc * 8, tadd, has_add, f);
+        const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x) + img + (size_t)cc * 8;
+        auto accum = [&](const u16x8_t& v) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float d = f[j] - piv[j];
+                float f = Cvt<DT>::to_f32(v[j]);
+                if (has_add) f = Cvt<DT>::to_f32(Cvt<DT>::from_f32(f + tadd[j]));
+                const float d = f - piv[j];
                 s[j] += d;
                 q[j] += d * d;
             }
+        };
+        int row = sc * a.rows + r;
+        // four independent 16-byte loads in flight per lane (a lane's rows are R rows apart)
+        for (; row + 3 * a.R < row1; row += 4 * a.R) {
+            const u16x8_t v0 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)row * a.C);
+            const u16x8_t v1 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(row + a.R) * a.C);
+            const u16x8_t v2 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(row + 2 * a.R) * a.C);
+            const u16x8_t v3 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(row + 3 * a.R) * a.C);
+            accum(v0); accum(v1); accum(v2); accum(v3);
         }
+        for (; row < row1; row += a.R) accum(*reinterpret_cast<const u16x8_t*>(xp + (size_t)row * a.C));
 #pragma unroll
         for (int j = 0; j < 8; ++j) sh[(size_t)r * a.C + cc * 8 + j] = make_float2(s[j], q[j]);
     }
@@ -168,17 +179,30 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArg
     }
     const int row1 = min(a.HW, (sc + 1) * a.rows);
     unsigned short* yp = reinterpret_cast<unsigned short*>(a.y);
-    for (int row = sc * a.rows + r; row < row1; row += a.R) {
-        const size_t e = img + (size_t)row * a.C + cc * 8;
-        float f[8];
-        nh_load8<DT>(a, e, tadd, has_add, f);
+    const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x);
+    auto apply = [&](const u16x8_t& v, size_t e) {
         u16x8_t o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float v = (f[j] - mean[j]) * ga[j] + be[j];
-            o[j] = Cvt<DT>::from_f32(a.act ? nh_silu(v) : v);
+            float f = Cvt<DT>::to_f32(v[j]);
+            if (has_add) f = Cvt<DT>::to_f32(Cvt<DT>::from_f32(f + tadd[j]));
+            const float w = (f - mean[j]) * ga[j] + be[j];
+            o[j] = Cvt<DT>::from_f32(a.act ? nh_silu(w) : w);
         }
         *reinterpret_cast<u16x8_t*>(yp + e) = o;
+    };
+    int row = sc * a.rows + r;
+    for (; row + 3 * a.R < row1; row += 4 * a.R) {
+        const size_t e0 = img + (size_t)row * a.C + cc * 8, st = (size_t)a.R * a.C;
+        const u16x8_t v0 = *reinterpret_cast<const u16x8_t*>(xp + e0);
+        const u16x8_t v1 = *reinterpret_cast<const u16x8_t*>(xp + e0 + st);
+        const u16x8_t v2 = *reinterpret_cast<const u16x8_t*>(xp + e0 + 2 * st);
+        const u16x8_t v3 = *reinterpret_cast<const u16x8_t*>(xp + e0 + 3 * st);
+        apply(v0, e0); apply(v1, e0 + st); apply(v2, e0 + 2 * st); apply(v3, e0 + 3 * st);
+    }
+    for (; row < row1; row += a.R) {
+        const size_t e = img + (size_t)row * a.C + cc * 8;
+        apply(*reinterpret_cast<const u16x8_t*>(xp + e), e);
     }
 }
 

@@ -402,5 +402,5 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
                                    _ptr(key_bias), Nk if key_bias is not None else 0, scale, _stream())
         _lib.check(rc, "pgn_attention_fwd")
 
-    _launch("attention", work, run)
+    _launch("attention" if D == 64 else f"attention_d{D}", work, run)
     return out

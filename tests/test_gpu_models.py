@@ -246,3 +246,29 @@ def test_generate_image_argument_errors_and_generator_path(stack):
     c = pipe.generate_image(image_tokens=toks, width=128, height=128, num_inference_steps=2, generator=gen,
                             output_type="latent")[0]
     assert _rel(a, c)[1] > 0.5       # a different seed is a different image
+
+
+def test_channels_last_and_nchw_modes_agree(stack):
+    # PigeonPixelDecoder keeps activations channels_last by default; the NCHW mode runs the same modules through the
+    # NCHW GroupNorm kernels.  Same weights, same input: equal up to the bf16 noise floor (different conv solvers).
+    pipe = stack["pipe"]
+    unet, vae = pipe.unet, pipe.vae
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(4, 4, 16, 20, generator=g).to(DEV, torch.bfloat16)
+    ctx = torch.randn(4, 256, 2048, generator=g).to(DEV, torch.bfloat16)
+    added = {"text_embeds": torch.randn(4, 1280, generator=g).to(DEV, torch.bfloat16),
+             "time_ids": torch.tensor([[160, 128, 0, 0, 160, 128]], device=DEV).repeat(4, 1)}
+    z = torch.randn(2, 4, 16, 20, generator=g).to(DEV, torch.bfloat16)
+    assert unet.channels_last and vae.channels_last
+    try:
+        a = unet(x, 500, encoder_hidden_states=ctx, added_cond_kwargs=added).sample
+        va = vae.decode(z).sample
+        unet.enable_channels_last(False)
+        vae.enable_channels_last(False)
+        b = unet(x, 500, encoder_hidden_states=ctx, added_cond_kwargs=added).sample
+        vb = vae.decode(z).sample
+    finally:
+        unet.enable_channels_last(True)
+        vae.enable_channels_last(True)
+    assert b.is_contiguous()
+    assert _rel(a, b)[1] < 0.02 and _rel(va, vb)[1] < 0.02
