@@ -165,10 +165,11 @@ int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const void* gamma
  * place (no head_to_batch_dim copy).  dtype: PGN_BF16 or PGN_F16 storage, fp32 softmax/accumulate.
  * key_bias: fp32 [B, Nk] additive bias broadcast over heads and queries (key padding:
  * lavit_for_pigeon.py:873-874 lowres path; modeling_decoder.py:100-102), or NULL.
- * Any Nq, Nk >= 1 (ragged tails handled).  D: any multiple of 8 up to 128 — 64 is the SDXL UNet (every level),
- * 88 the token decoder (modeling_decoder.py:44-109, 16 heads x 88), 40 / 80 the SD-1.5 lowres UNet; head dims other
- * than 64 / 128 are zero-filled to the next of the two inside the kernel (no padded copies).  D > 128 (the VAE's
- * single 512-wide head, SD-1.5's 160) -> PGN_ERR_UNSUPPORTED.
+ * Any Nq, Nk >= 1 (ragged tails handled).  D: any multiple of 8 up to 256 — 64 is the SDXL UNet (every level),
+ * 88 the token decoder (modeling_decoder.py:44-109, 16 heads x 88), 40 / 80 / 160 the SD-1.5 lowres UNet; head dims
+ * other than 64 / 128 / 256 are zero-filled to the next of the three inside the kernel (no padded copies); above 128
+ * the kernel runs one wavefront per SIMD (correct, not tuned).  D > 256 (the VAE's single 512-wide head) ->
+ * PGN_ERR_UNSUPPORTED.
  * Algorithmic work: 4*B*H*Nq*Nk*D flop.
  */
 int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H, int Nq,

@@ -22,8 +22,8 @@
 namespace {
 
 constexpr int ATT_BN = 64;       // keys per tile
-// Head dims: the kernel is instantiated for a PADDED head dim DP of 64 or 128; a head dim D < DP (D % 8 == 0: the
-// token decoder's 88, SD-1.5's 40 / 80) is zero-filled up to DP on the way into registers / LDS (zero q and k columns
+// Head dims: the kernel is instantiated for a PADDED head dim DP of 64, 128 or 256 (256: one wavefront per SIMD, for
+// SD-1.5's 160-wide heads only); a head dim D < DP (D % 8 == 0: the token decoder's 88, SD-1.5's 40 / 80 / 160) is zero-filled up to DP on the way into registers / LDS (zero q and k columns
 // add nothing to the scores, zero v columns are never stored), so callers pass their tensors as they are.
 // a workgroup = NWAVES wave64, 32 query rows each: NWAVES = 8 (256 rows, 2 waves per SIMD) for long key sequences,
 // NWAVES = 4 (128 rows, several workgroups per CU) when the key loop is short and prologue latency dominates
@@ -72,7 +72,7 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 template <int DP>
 __device__ __forceinline__ int k_lds_off(int row, int ch) {
     if constexpr (DP == 64) return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
-    else return row * 256 + ((ch ^ (row & 15)) << 4);
+    else return row * (2 * DP) + ((ch ^ (row & 15)) << 4);   // DP 128 / 256: the XOR stays inside a 256-byte line
 }
 // V: 8-key x 32-dim sub-tiles of 512 bytes (what ds_read_b64_tr_b16 transposes), DP/32 of them per 8-key group
 template <int DP>
@@ -334,7 +334,7 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     if (q == nullptr || k == nullptr || v == nullptr || out == nullptr) return PGN_ERR_INVALID;
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || D <= 0) return PGN_ERR_INVALID;
     if (dtype != PGN_BF16 && dtype != PGN_F16) return PGN_ERR_UNSUPPORTED;
-    if (D > 128 || (D & 7) != 0) return PGN_ERR_UNSUPPORTED;   // head dims 8..128 in steps of 8 (16-byte row chunks)
+    if (D > 256 || (D & 7) != 0) return PGN_ERR_UNSUPPORTED;   // head dims 8..256 in steps of 8 (16-byte row chunks)
     // 16-byte vector loads of q/k/v rows, 8-byte stores of out rows
     const int64_t st[12] = {q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh};
     for (int i = 0; i < 12; ++i)
@@ -369,7 +369,9 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
             else hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 64, false>), grid, block, 0, s, a);        \
         } else if (D < 64) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 64, true>), grid, block, 0, s, a); \
         else if (D == 128) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 128, false>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 128, true>), grid, block, 0, s, a);           \
+        else if (D < 128) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 128, true>), grid, block, 0, s, a); \
+        else if (D == 256) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 1, 256, false>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 1, 256, true>), grid, block, 0, s, a);           \
     } while (0)
     if (dtype == PGN_BF16) {
         if (key_bias != nullptr) PGN_ATT_LAUNCH(PGN_BF16, true);

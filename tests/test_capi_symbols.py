@@ -49,8 +49,8 @@ def test_argument_validation_happens_before_any_launch():
     buf = ctypes.create_string_buffer(64)
     p = ctypes.addressof(buf)
     p16 = (p + 15) & ~15
-    # head_dim above 128 or not a multiple of 8 -> unsupported, 3-channel groups that do not divide -> invalid
-    assert lib.pgn_attention_fwd(p16, p16, p16, p16, 1, 1, 1, 1, 1, 136, *([8] * 12), None, 0, 0.1, None) == -2
+    # head_dim above 256 or not a multiple of 8 -> unsupported, 3-channel groups that do not divide -> invalid
+    assert lib.pgn_attention_fwd(p16, p16, p16, p16, 1, 1, 1, 1, 1, 264, *([8] * 12), None, 0, 0.1, None) == -2
     assert lib.pgn_attention_fwd(p16, p16, p16, p16, 1, 1, 1, 1, 1, 44, *([8] * 12), None, 0, 0.1, None) == -2
     assert lib.pgn_groupnorm_silu(p16, 1, p16, 1, None, None, 1, 1, 30, 16, 32, 1e-5, 1, None) == -1
     # workspace query is host-only arithmetic; a too-small workspace is refused before any launch

@@ -437,6 +437,9 @@ ATTN_D_CASES = [
     (2, 8, 256, 77, 80, True),       # SD-1.5 level 2 with encoder_attention_mask
     (1, 3, 65, 130, 8, False),
     (1, 2, 130, 65, 120, True),
+    (2, 8, 64, 77, 160, True),       # SD-1.5 levels 3 / mid: 8 heads x 160 (one wavefront per SIMD instantiation)
+    (2, 8, 256, 256, 160, False),
+    (1, 2, 300, 300, 256, False),
 ]
 
 
