@@ -197,7 +197,8 @@ def _ln32(x, w, b, eps=1e-5):
 
 def token_decoder_forward(p: Policy, sd_in, x, token_nums, num_heads=16):
     """HighresVQDecoder.forward, modeling_decoder.py:302-337 (Block :133-137, SelfAttention :58-71,
-    CrossAttention :90-109, AttentionPool2d :150-177), written over the state dict."""
+    CrossAttention :90-109, AttentionPool2d :150-177), written over the state dict.  A state dict holding `unet_proj`
+    is the lowres VQDecoder (:180-254) and returns its single [B, 256, 768] tensor."""
     sd = SD(sd_in)
     H = num_heads
     x = p.lin(x, sd["in_proj.weight"], sd["in_proj.bias"])                                   # :305
@@ -234,6 +235,8 @@ def token_decoder_forward(p: Policy, sd_in, x, token_nums, num_heads=16):
     q = _ln32(q, sd["norm.weight"], sd["norm.bias"])                                          # :328
     rec = p.lin(torch.tanh(p.lin(q, sd["decode_task_layer.0.weight"], sd["decode_task_layer.0.bias"])),
                 sd["decode_task_layer.2.weight"], sd["decode_task_layer.2.bias"])             # :330
+    if "unet_proj.weight" in sd:     # lowres VQDecoder.forward, modeling_decoder.py:222-254 (same trunk, :250-254)
+        return p.lin(rec, sd["unet_proj.weight"], sd["unet_proj.bias"])
     prompt = torch.cat([p.lin(rec, sd["unet_proj_1.weight"], sd["unet_proj_1.bias"]),
                         p.lin(rec, sd["unet_proj_2.weight"], sd["unet_proj_2.bias"])], dim=-1)  # :332-334
     # AttentionPool2d :150-177 (multi_head_attention_forward with separate projection weights)

@@ -140,3 +140,42 @@ def generate_image_ref(policy: Policy, image_tokens: List[torch.Tensor], codeboo
         images = (img * 255).round().astype("uint8")                                            # :929
     return {"latents_per_step": per_step, "latents": latents, "prompt_embeds": prompt_embeds, "pooled": pooled,
             "images": images}
+
+
+def pixel_decoding_origin_ref(policy: Policy, image_tokens: List[torch.Tensor], codebook: torch.Tensor,
+                              decoder_sd: Dict[str, torch.Tensor], unet_sd: Dict[str, torch.Tensor], unet_cfg: dict,
+                              scheduler, uncond_embeddings: torch.Tensor, noise: torch.Tensor, width=512, height=512,
+                              num_inference_steps=50, guidance_scale=5.0, decoder_heads=16, vae_sd=None, vae_cfg=None):
+    """lavit_for_pigeon.py:822-895 (the SD-1.5 `lowres` decoder) with explicit `noise` in place of the CPU
+    torch.randn(generator=...) of :858-860.  `uncond_embeddings` is the `[1, n_u, 768]` buffer of :168."""
+    cdt = policy.compute
+    emb, token_nums = ops_ref.token_gather_ref(image_tokens, codebook, cdt)                     # :837 / :897-920
+    xrec = models_ref.token_decoder_forward(policy, decoder_sd, emb, token_nums, decoder_heads)
+    batch_size = len(xrec)                                                                      # :838
+    _, num_tokens, C = xrec.shape
+    hidden_uncond = torch.zeros(batch_size, num_tokens, C, dtype=xrec.dtype)                    # :843
+    unc = uncond_embeddings[0].to(xrec.dtype)                                                   # :844
+    hidden_uncond[:, :len(unc)] = unc                                                           # :845
+    encoder_mask = torch.ones(batch_size, num_tokens, dtype=torch.long)                         # :848
+    uncond_mask = torch.zeros(batch_size, num_tokens, dtype=torch.long)
+    uncond_mask[:, :len(unc)] = 1                                                               # :850
+    text_embeddings = torch.cat([hidden_uncond, xrec])                                          # :855
+    text_mask = torch.cat([uncond_mask.bool(), encoder_mask.bool()])                            # :856
+    latents = noise.float() * scheduler.init_noise_sigma                                        # :858-862
+    assert latents.shape == (batch_size, unet_cfg["in_channels"], height // 8, width // 8)
+    scheduler.set_timesteps(num_inference_steps)                                                # :864
+    per_step = []
+    for t in scheduler.timesteps:                                                               # :866
+        x = scheduler.scale_model_input(torch.cat([latents] * 2), t)                            # :868-870
+        noise_pred = models_ref.unet_forward(policy, unet_sd, unet_cfg, x, t, text_embeddings,
+                                             encoder_attention_mask=text_mask)                  # :873-874
+        guided = ops_ref.cfg_combine_ref(noise_pred, guidance_scale)                            # :877-878
+        latents = scheduler.step(guided, t, latents)[0]                                         # :881
+        per_step.append(latents.clone())
+    images = None
+    if vae_sd is not None:
+        # :883-884 — inside the autocast region: the division is fp32, the decoder computes in the compute dtype
+        img = models_ref.vae_decode(policy, vae_sd, vae_cfg, latents / vae_cfg["scaling_factor"])
+        img = (img.float() / 2 + 0.5).clamp(0, 1)                                               # :886-887
+        images = (img.permute(0, 2, 3, 1).numpy() * 255).round().astype("uint8")                # :888, :929
+    return {"latents_per_step": per_step, "latents": latents, "xrec": xrec, "images": images}

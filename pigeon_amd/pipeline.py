@@ -42,7 +42,8 @@ class PigeonPixelDecoder:
     """Owns the frozen decoder stack (codebook, token decoder, UNet, scheduler, VAE) on one GPU."""
 
     def __init__(self, codebook: torch.Tensor, tokenizer_decoder, unet, vae, scheduler=None,
-                 model_dtype: str = "bf16", device: Union[str, torch.device] = "cuda", channels_last: bool = True):
+                 model_dtype: str = "bf16", device: Union[str, torch.device] = "cuda", channels_last: bool = True,
+                 pixel_decoding: str = "highres", uncond_embeddings: Optional[torch.Tensor] = None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("PigeonPixelDecoder runs on an MI355X (device 'cuda:N'); there is no CPU path")
@@ -52,7 +53,14 @@ class PigeonPixelDecoder:
         self.unet = unet.to(self.device, self.dtype).eval().requires_grad_(False)
         self.vae = None if vae is None else vae.to(self.device, self.dtype).eval().requires_grad_(False)
         self.scheduler = scheduler if scheduler is not None else DDIMScheduler()
-        self.pixel_decoding = "highres"
+        if pixel_decoding not in ("highres", "lowres"):
+            raise ValueError("pixel_decoding is 'highres' or 'lowres'")
+        self.pixel_decoding = pixel_decoding                       # lavit_for_pigeon.py:163
+        if pixel_decoding == "lowres":
+            if uncond_embeddings is None:
+                raise ValueError("pixel_decoding='lowres' needs the `uncond_embeddings` buffer "
+                                 "(pixel_decoding/uncond_embeddings.bin, lavit_for_pigeon.py:168)")
+            self.uncond_embeddings = uncond_embeddings.detach().to(self.device)
         from . import enable_tuned_gemms
         self.tuned_gemms = enable_tuned_gemms()
         if channels_last:
@@ -63,6 +71,7 @@ class PigeonPixelDecoder:
     # ---- :897-920 ------------------------------------------------------------------------------
     @torch.no_grad()
     def generate_image_embeds(self, image_tokens: Union[Sequence[torch.Tensor], torch.Tensor]):
+        """-> (prompt_embeds, pooled) from the highres decoder, `xrec` [B, 256, 768] from the lowres one."""
         toks = image_tokens if isinstance(image_tokens, torch.Tensor) else [t.to(self.device) for t in image_tokens]
         g = ops.token_gather(toks, self.codebook, out_dtype=self.dtype, packed=False, padded=True)
         return self.tokenizer_decoder.forward_padded(g["padded"], g["mask"])
@@ -88,6 +97,10 @@ class PigeonPixelDecoder:
         if image_tokens is None:
             raise NotImplementedError("token generation (the LLaMA stage) is outside the accelerated path: pass "
                                       "`image_tokens` as inference.py:389-399 does")
+        if self.pixel_decoding == "lowres":                        # :702-703 (same positional hand-over)
+            return self.pixel_decoding_origin(image_tokens, width, height, num_inference_steps,
+                                              guidance_scale_for_diffusion, generator, latents=latents,
+                                              output_type=output_type, callback=callback)
         prompt_embeds, pooled_prompt_embeds = self.generate_image_embeds(image_tokens)
         negative_prompt_embeds = torch.zeros_like(prompt_embeds)
         negative_pooled_prompt_embeds = torch.zeros_like(pooled_prompt_embeds)
@@ -130,15 +143,62 @@ class PigeonPixelDecoder:
         images = self.decode_latents(latents, output_type)
         return images, prompt_embeds, pooled_prompt_embeds
 
+    # ---- :822-895 ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def pixel_decoding_origin(self, image_tokens, width: int = 512, height: int = 512, num_inference_steps: int = 50,
+                              guidance_scale_for_decoder: float = 5.0, generator: Optional[torch.Generator] = None,
+                              latents: Optional[torch.Tensor] = None, output_type: str = "pil",
+                              callback: Optional[Callable[[int, int, torch.Tensor], None]] = None):
+        """The original LaVIT pixel decoder (SD-1.5 UNet): learned unconditional embeddings in the first rows of an
+        otherwise zero context, boolean key masks for both CFG halves, noise drawn on the HOST (:858-860 has no
+        `device=`, so `generator` is a CPU generator here) and a 2-tuple return `(images, xrec)`.  Keyword extensions
+        as in `generate_image`."""
+        if self.pixel_decoding != "lowres":
+            raise RuntimeError("pixel_decoding_origin needs pixel_decoding='lowres' (VQDecoder + uncond_embeddings)")
+        xrec = self.generate_image_embeds(image_tokens)                                        # :837
+        batch_size, num_tokens, C = xrec.shape
+        uncond = self.uncond_embeddings[0].to(xrec.dtype)                                      # :844
+        n_u = len(uncond)
+        encoder_hidden_uncond = torch.zeros(batch_size, num_tokens, C, dtype=xrec.dtype, device=self.device)
+        encoder_hidden_uncond[:, :n_u] = uncond                                                # :845
+        encoder_mask = torch.ones(batch_size, num_tokens, dtype=torch.bool, device=self.device)
+        uncond_encoder_mask = torch.zeros(batch_size, num_tokens, dtype=torch.bool, device=self.device)
+        uncond_encoder_mask[:, :n_u] = True                                                    # :850
+        text_embeddings = torch.cat([encoder_hidden_uncond, xrec])                             # :855
+        text_embeddings_mask = torch.cat([uncond_encoder_mask, encoder_mask])                  # :856
+
+        shape = (batch_size, self.unet.config.in_channels, height // 8, width // 8)
+        if latents is None:
+            latents = torch.randn(shape, generator=generator)                                  # host noise, :858-860
+        elif tuple(latents.shape) != shape:
+            raise ValueError(f"latents must have shape {shape}")
+        latents = (latents.float() * self.scheduler.init_noise_sigma).to(self.device)          # :861-862
+        self.scheduler.set_timesteps(num_inference_steps, device=self.device)                  # :864
+        for i, t in enumerate(list(self.scheduler._host_timesteps)):                           # :866
+            latent_model_input = ops.cfg_expand_scale(latents, self.unet.dtype, self.scheduler.scale_divisor(t))
+            noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings,
+                                   encoder_attention_mask=text_embeddings_mask).sample          # :873-874
+            latents = self.scheduler.step_cfg(noise_pred, t, latents, guidance_scale_for_decoder).prev_sample
+            if callback is not None:
+                callback(i, t, latents)
+        if output_type == "latent":
+            return latents, xrec
+        # :883-884 run inside the autocast region: the division is fp32, the first convolution casts to bf16
+        return self.decode_latents(latents, output_type, divide_in_fp32=True), xrec
+
     # ---- :766-787 ------------------------------------------------------------------------------
     @torch.no_grad()
-    def decode_latents(self, latents: torch.Tensor, output_type: str = "pil", chunk: int = 1):
+    def decode_latents(self, latents: torch.Tensor, output_type: str = "pil", chunk: int = 1,
+                       divide_in_fp32: bool = False):
         """VAE decode + post-process.  Images are decoded `chunk` at a time: samples are independent in the decoder,
         and a 16 x 256 x 1024 x 1024 activation exceeds the 2^31-element limit of torch's nearest-upsample launch."""
         if self.vae is None:
             raise RuntimeError("no VAE attached")
         vae_dtype = next(iter(self.vae.post_quant_conv.parameters())).dtype
-        z = latents.to(vae_dtype) / self.vae.config.scaling_factor
+        if divide_in_fp32:
+            z = (latents / self.vae.config.scaling_factor).to(vae_dtype)
+        else:
+            z = latents.to(vae_dtype) / self.vae.config.scaling_factor                         # :773-774
         outs = []
         for i in range(0, z.shape[0], max(1, chunk)):
             image = self.vae.decode(z[i:i + chunk]).sample

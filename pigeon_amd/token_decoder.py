@@ -14,6 +14,8 @@ order; the reference's per-sample Python pad loop :315-317 and its `.tolist()` /
     (host-logic tests against the reference's golden vectors) the same module evaluates with torch ops;
   * the attention pool evaluates only the one query row whose output is used (`x[0]`, :177).
 `forward(x, token_num)` keeps the reference signature (packed rows + counts).
+`VQDecoder` is the lowres twin (modeling_decoder.py:180-254, `tokenizer_decoder.bin`) used by
+`pixel_decoding_origin` (lavit_for_pigeon.py:822-895).
 """
 from functools import partial
 from typing import Optional
@@ -128,7 +130,10 @@ class _AttentionPool(nn.Module):
         return self.c_proj(o.reshape(B, C))
 
 
-class HighresVQDecoder(nn.Module):
+class _VQDecoderBase(nn.Module):
+    """Trunk shared by the two decoders (modeling_decoder.py:181-203 == :258-280): in_proj, pos / query embeddings,
+    the blocks, the final norm and `decode_task_layer`."""
+
     def __init__(self, img_size=224, patch_size=14, in_chans=32, embed_dim=1408, depth=12, num_heads=16,
                  mlp_ratio=4.3637, qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
                  norm_layer=partial(_LayerNormFp32, eps=1e-5), **kwargs):
@@ -146,15 +151,11 @@ class HighresVQDecoder(nn.Module):
         self.decoder_out_dim = 1408
         self.decode_task_layer = nn.Sequential(nn.Linear(embed_dim, embed_dim), nn.Tanh(),
                                                nn.Linear(embed_dim, self.decoder_out_dim))
-        self.unet_proj_1 = nn.Linear(self.decoder_out_dim, 768)
-        self.unet_proj_2 = nn.Linear(self.decoder_out_dim, 1280)
-        self.unet_attnpool = _AttentionPool(self.num_patches, self.decoder_out_dim, num_heads, 1280)
 
     def get_num_layers(self):
         return len(self.blocks)
 
-    def forward_padded(self, x_pad: torch.Tensor, mask: torch.Tensor):
-        """x_pad [B, L, in_chans] (rows past each sample's token count are ignored), mask [B, L] in {0, 1}."""
+    def _visual_rec(self, x_pad: torch.Tensor, mask: torch.Tensor):
         B, L, _ = x_pad.shape
         if L > self.num_patches:
             raise ValueError(f"at most {self.num_patches} tokens per sample")
@@ -166,9 +167,7 @@ class HighresVQDecoder(nn.Module):
         q = self.query_embed.expand(B, -1, -1)
         for blk in self.blocks:
             q = blk(q, x, bias)
-        rec = self.decode_task_layer(self.norm(q))
-        prompt_embeds = torch.cat([self.unet_proj_1(rec), self.unet_proj_2(rec)], dim=-1)
-        return prompt_embeds, self.unet_attnpool(rec)
+        return self.decode_task_layer(self.norm(q))
 
     def forward(self, x: torch.Tensor, token_num: torch.Tensor):
         """Reference signature: x [sum(token_num), in_chans] packed rows, token_num int64 [B]."""
@@ -184,12 +183,42 @@ class HighresVQDecoder(nn.Module):
         return self.forward_padded(x_pad, mask)
 
 
+class HighresVQDecoder(_VQDecoderBase):
+    """modeling_decoder.py:257-337 -> (prompt_embeds [B, 256, 2048], pooled [B, 1280])."""
+
+    def __init__(self, img_size=224, patch_size=14, in_chans=32, embed_dim=1408, depth=12, num_heads=16, **kwargs):
+        super().__init__(img_size, patch_size, in_chans, embed_dim, depth, num_heads, **kwargs)
+        self.unet_proj_1 = nn.Linear(self.decoder_out_dim, 768)
+        self.unet_proj_2 = nn.Linear(self.decoder_out_dim, 1280)
+        self.unet_attnpool = _AttentionPool(self.num_patches, self.decoder_out_dim, num_heads, 1280)
+
+    def forward_padded(self, x_pad: torch.Tensor, mask: torch.Tensor):
+        """x_pad [B, L, in_chans] (rows past each sample's token count are ignored), mask [B, L] in {0, 1}."""
+        rec = self._visual_rec(x_pad, mask)
+        prompt_embeds = torch.cat([self.unet_proj_1(rec), self.unet_proj_2(rec)], dim=-1)
+        return prompt_embeds, self.unet_attnpool(rec)
+
+
+class VQDecoder(_VQDecoderBase):
+    """The original (SD-1.5, `pixel_decoding='lowres'`) decoder, modeling_decoder.py:180-254: same trunk, one
+    projection to the 768-wide SD-1.5 cross-attention context -> visual_rec [B, 256, 768]."""
+
+    def __init__(self, img_size=224, patch_size=14, in_chans=32, embed_dim=1408, depth=12, num_heads=16, **kwargs):
+        super().__init__(img_size, patch_size, in_chans, embed_dim, depth, num_heads, **kwargs)
+        self.unet_proj = nn.Linear(self.decoder_out_dim, 768)
+
+    def forward_padded(self, x_pad: torch.Tensor, mask: torch.Tensor):
+        return self.unet_proj(self._visual_rec(x_pad, mask))
+
+
 def build_tokenizer_decoder(model_path: str = "", pixel_decoding: str = "highres", depth: int = 12):
-    """modeling_decoder.py:340-351 for the highres decoder; weights via torch.load(weights_only=True)."""
+    """modeling_decoder.py:340-351; weights via torch.load(weights_only=True)."""
     import os
-    if pixel_decoding != "highres":
-        raise NotImplementedError("only the highres pixel decoder is on the accelerated path")
-    model = HighresVQDecoder(depth=depth)
-    weight_path = os.path.join(model_path, "visual_tokenizer", "highres_tokenizer_decoder.bin")
+    if pixel_decoding == "lowres":
+        model = VQDecoder(depth=depth)
+        weight_path = os.path.join(model_path, "visual_tokenizer", "tokenizer_decoder.bin")
+    else:
+        model = HighresVQDecoder(depth=depth)
+        weight_path = os.path.join(model_path, "visual_tokenizer", "highres_tokenizer_decoder.bin")
     model.load_state_dict(torch.load(weight_path, map_location="cpu", weights_only=True))
     return model

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/token_decoder_depth2.npz by RUNNING THE REFERENCE'S OWN MODULE
-(/root/reference/Pigeon/models/modeling_decoder.py, HighresVQDecoder) in the build container.
+"""Generate tests/golden/token_decoder_depth2.npz and vq_decoder_lowres_depth2.npz by RUNNING THE REFERENCE'S OWN MODULE
+(/root/reference/Pigeon/models/modeling_decoder.py, HighresVQDecoder and VQDecoder) in the build container.
 
 The reference file is loaded by path; its only missing import is `timm.models.layers` (three names it never uses,
 modeling_decoder.py:7), provided here as an empty placeholder module.  Nothing from the reference is copied into the
@@ -59,6 +59,20 @@ def main():
     )
     print("wrote", out, os.path.getsize(out), "bytes; token_nums", nums.tolist(),
           "prompt std", float(prompt.std()), "pooled std", float(pooled.std()))
+
+    # the lowres twin (modeling_decoder.py:180-254), same inputs, its own seeded weights
+    low = ref.VQDecoder(depth=2).eval()
+    low.load_state_dict(weights.synth_like(low, seed=321))
+    with torch.no_grad():
+        xrec = low(emb, nums)
+    out = os.path.join(ROOT, "tests", "golden", "vq_decoder_lowres_depth2.npz")
+    np.savez_compressed(
+        out,
+        tokens=torch.stack(tokens).numpy(), token_nums=nums.numpy(),
+        rows=rows.numpy(), xrec_rows=xrec[:, rows].numpy().astype(np.float32),
+        xrec_sum=xrec.double().sum(dim=(1, 2)).numpy(), xrec_abs_sum=xrec.double().abs().sum(dim=(1, 2)).numpy(),
+    )
+    print("wrote", out, os.path.getsize(out), "bytes; xrec", tuple(xrec.shape), "std", float(xrec.std()))
 
 
 if __name__ == "__main__":

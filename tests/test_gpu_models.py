@@ -272,3 +272,87 @@ def test_channels_last_and_nchw_modes_agree(stack):
         vae.enable_channels_last(True)
     assert b.is_contiguous()
     assert _rel(a, b)[1] < 0.02 and _rel(va, vb)[1] < 0.02
+
+
+# ---- lowres decoder: pixel_decoding_origin (lavit_for_pigeon.py:822-895) -----------------------------------------
+TINY_SD15 = dict(down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+                 up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+                 block_out_channels=(64, 128, 128), attention_head_dim=2, transformer_layers_per_block=1,
+                 cross_attention_dim=768, layers_per_block=1, use_linear_projection=False, addition_embed_type=None,
+                 addition_time_embed_dim=None, projection_class_embeddings_input_dim=None, sample_size=16)
+SD15_SCHED = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000,
+                  steps_offset=1, clip_sample=False, set_alpha_to_one=False, timestep_spacing="leading")
+
+
+@pytest.fixture(scope="module")
+def lowres_stack():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pigeon_amd.pipeline import PigeonPixelDecoder
+    from pigeon_amd.schedulers import DDIMScheduler
+    from pigeon_amd.token_decoder import VQDecoder
+    from pigeon_amd.unet import UNet2DConditionModel
+    from pigeon_amd.vae import AutoencoderKL
+    unet = UNet2DConditionModel(**TINY_SD15)     # head dims 32 / 64 / 64 with 2 heads, conv proj_in / proj_out
+    unet_sd = weights.synth_like(unet, 21)
+    unet.load_state_dict(unet_sd)
+    dec = VQDecoder(depth=2)
+    dec_sd = weights.synth_like(dec, 321)
+    dec.load_state_dict(dec_sd)
+    vae = AutoencoderKL(**dict(TINY_VAE, scaling_factor=0.18215))
+    vae_sd = weights.synth_like(vae, 5)
+    vae.load_state_dict(vae_sd)
+    codebook = weights.synth_codebook()
+    uncond = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(77)) * 0.6   # the buffer of :168
+    pipe = PigeonPixelDecoder(codebook, dec, unet, vae, DDIMScheduler(**SD15_SCHED), "bf16", DEV,
+                              pixel_decoding="lowres", uncond_embeddings=uncond)
+    bf = lambda sd: {k: v.to(torch.bfloat16) for k, v in sd.items()}
+    return dict(pipe=pipe, unet_cfg=dict(unet.config), unet_sd=bf(unet_sd), dec_sd=bf(dec_sd), vae_sd=bf(vae_sd),
+                vae_cfg=dict(vae.config), codebook=codebook, unet_sd32=unet_sd, dec_sd32=dec_sd, uncond=uncond)
+
+
+def test_pixel_decoding_origin_per_step_latents_match_oracle(lowres_stack):
+    st = lowres_stack
+    pipe = st["pipe"]
+    tokens = weights.synth_tokens(3, seed=5)
+    steps, H, W = 4, 128, 160
+    noise = torch.randn(3, 4, H // 8, W // 8, generator=torch.Generator().manual_seed(123))
+    got_steps = []
+    images, xrec = pipe.pixel_decoding_origin([t.to(DEV) for t in tokens], width=W, height=H,
+                                              num_inference_steps=steps, guidance_scale_for_decoder=5.0, latents=noise,
+                                              output_type="uint8",
+                                              callback=lambda i, t, x: got_steps.append(x.cpu().clone()))
+    kw = dict(width=W, height=H, num_inference_steps=steps, guidance_scale=5.0)
+    ref = pipeline_ref.pixel_decoding_origin_ref(Policy(torch.bfloat16), tokens, st["codebook"], st["dec_sd"],
+                                                 st["unet_sd"], st["unet_cfg"], pipeline_ref.DDIMRef(**SD15_SCHED),
+                                                 st["uncond"], noise, vae_sd=st["vae_sd"], vae_cfg=st["vae_cfg"], **kw)
+    ref32 = pipeline_ref.pixel_decoding_origin_ref(Policy(torch.float32), tokens, st["codebook"], st["dec_sd32"],
+                                                   st["unet_sd32"], st["unet_cfg"], pipeline_ref.DDIMRef(**SD15_SCHED),
+                                                   st["uncond"], noise, **kw)
+    assert xrec.shape == (3, 256, 768) and xrec.dtype == torch.bfloat16
+    _calibrated(xrec, ref["xrec"], ref32["xrec"], 0.03, "lowres xrec")
+    assert len(got_steps) == steps
+    for i, (a, b, c) in enumerate(zip(got_steps, ref["latents_per_step"], ref32["latents_per_step"])):
+        _calibrated(a, b, c, 0.08, f"lowres latents after step {i}")
+    d = np.abs(images.cpu().numpy().astype(int) - ref["images"].astype(int))
+    assert images.shape == (3, H // 4, W // 4, 3) and d.mean() < 3.0 and np.percentile(d, 99) <= 12, (d.mean(), d.max())
+
+
+def test_lowres_facade_dispatch_and_host_noise(lowres_stack):
+    # generate_image hands over to pixel_decoding_origin (:702-703); noise comes from a HOST generator (:858-860),
+    # so a seeded run is reproducible from the CPU stream alone and equals an explicit-latents run
+    pipe = lowres_stack["pipe"]
+    toks = weights.synth_tokens(2, seed=8)
+    out = pipe.generate_image(image_tokens=toks, width=128, height=128, num_inference_steps=2,
+                              guidance_scale_for_diffusion=5.0, generator=torch.Generator().manual_seed(123),
+                              output_type="latent")
+    assert len(out) == 2 and out[0].shape == (2, 4, 16, 16) and out[1].shape == (2, 256, 768)
+    noise = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(123))
+    b = pipe.pixel_decoding_origin(toks, 128, 128, 2, 5.0, latents=noise, output_type="latent")[0]
+    assert _rel(out[0], b)[1] < 0.06
+    pil, _ = pipe.pixel_decoding_origin(toks, 128, 128, 1, 5.0, generator=torch.Generator().manual_seed(1))
+    assert len(pil) == 2 and pil[0].size == (32, 32)
+    from pigeon_amd.pipeline import PigeonPixelDecoder
+    with pytest.raises(ValueError):
+        PigeonPixelDecoder(lowres_stack["codebook"], pipe.tokenizer_decoder, pipe.unet, None, None, "bf16", DEV,
+                           pixel_decoding="lowres")

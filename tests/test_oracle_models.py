@@ -56,6 +56,40 @@ def test_product_token_decoder_host_logic_matches_reference_golden(golden, decod
     _check_against_golden(golden, prompt2, pooled2, atol=5e-5)
 
 
+def test_lowres_vq_decoder_oracle_and_product_match_reference_golden(golden_dir):
+    # tests/golden/vq_decoder_lowres_depth2.npz: outputs of the reference's own VQDecoder (modeling_decoder.py:180-254)
+    from pigeon_amd.token_decoder import VQDecoder
+    g = np.load(os.path.join(golden_dir, "vq_decoder_lowres_depth2.npz"))
+    m = VQDecoder(depth=2).eval()
+    sd = weights.synth_like(m, seed=321)
+    m.load_state_dict(sd)
+    tokens = list(torch.from_numpy(g["tokens"]))
+    emb, nums = ops_ref.token_gather_ref(tokens, weights.synth_codebook(), torch.float32)
+    assert nums.tolist() == g["token_nums"].tolist()
+    rows = torch.from_numpy(g["rows"])
+    want_sum = g["xrec_sum"]
+    with torch.no_grad():
+        pad, mask = ops_ref.pad_and_mask_ref(emb, nums, pad_len=256)
+        outs = {"oracle": models_ref.token_decoder_forward(Policy(torch.float32), sd, emb, nums),
+                "product packed": m(emb, nums), "product padded": m.forward_padded(pad, mask)}
+    for what, xrec in outs.items():
+        assert xrec.shape == (4, 256, 768), what
+        assert np.allclose(xrec[:, rows].numpy(), g["xrec_rows"], atol=5e-5), what
+        assert np.allclose(xrec.double().sum(dim=(1, 2)).numpy(), want_sum, atol=5e-5 * xrec[0].numel() ** 0.5 * 4), what
+
+
+def test_build_tokenizer_decoder_reads_the_reference_file_layout(tmp_path):
+    # modeling_decoder.py:340-351: visual_tokenizer/{highres_tokenizer_decoder,tokenizer_decoder}.bin
+    from pigeon_amd.token_decoder import HighresVQDecoder, VQDecoder, build_tokenizer_decoder
+    (tmp_path / "visual_tokenizer").mkdir()
+    for cls, name, mode in ((HighresVQDecoder, "highres_tokenizer_decoder.bin", "highres"),
+                            (VQDecoder, "tokenizer_decoder.bin", "lowres")):
+        sd = weights.synth_like(cls(depth=1), seed=3)
+        torch.save(sd, tmp_path / "visual_tokenizer" / name)
+        m = build_tokenizer_decoder(str(tmp_path), pixel_decoding=mode, depth=1)
+        assert isinstance(m, cls) and torch.equal(m.state_dict()["in_proj.weight"], sd["in_proj.weight"])
+
+
 def _nparams(m):
     return sum(p.numel() for p in m.parameters())
 
