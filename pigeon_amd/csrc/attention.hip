@@ -119,8 +119,11 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
     // ---- staging assignment: thread -> (key row, 16-byte chunk) of the K and V tiles
     const int srow = tid / NCH, sch = tid % NCH;   // + i * SROWS rows for the i-th staged chunk
     const bool sch_ok = !PAD || sch * 8 < a.D;     // chunks past the real head dim are staged as zeros
-    const unsigned short* kp = a.k + b * a.k_sb + h * a.k_sh + sch * 8;
-    const unsigned short* vp = a.v + b * a.v_sb + h * a.v_sh + sch * 8;
+    // K / V addressing: a wave-uniform 64-bit base per (batch, head) in SGPRs plus 32-bit per-thread byte offsets
+    // (the host refuses key slices of 4 GiB and more), so a staged row costs one v_add_u32 per tile.
+    const char* kbase = reinterpret_cast<const char*>(a.k + b * a.k_sb + h * a.k_sh);
+    const char* vbase = reinterpret_cast<const char*>(a.v + b * a.v_sb + h * a.v_sh);
+    const unsigned k_rowb = (unsigned)a.k_sn * 2u, v_rowb = (unsigned)a.v_sn * 2u;   // bytes per key row
     int k_woff[NSTAGE], v_woff[NSTAGE];
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i) {
@@ -130,16 +133,18 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
     const float* bp = HAS_BIAS ? a.bias + b * a.bias_sb : nullptr;
 
     const int nt = (a.Nk + ATT_BN - 1) / ATT_BN;
+    const bool ragged = (a.Nk & (ATT_BN - 1)) != 0;
+    const int nfull = ragged ? nt - 1 : nt;
 
     u16x8_t kreg[NSTAGE], vreg[NSTAGE];
     float breg = 0.f;
-    auto stage_load = [&](int t) {
+    auto stage_load = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NSTAGE; ++i) {
             const int key = t * ATT_BN + srow + i * SROWS;
             if (key < a.Nk && sch_ok) {
-                kreg[i] = *reinterpret_cast<const u16x8_t*>(kp + (long long)key * a.k_sn);
-                vreg[i] = *reinterpret_cast<const u16x8_t*>(vp + (long long)key * a.v_sn);
+                kreg[i] = *reinterpret_cast<const u16x8_t*>(kbase + ((unsigned)key * k_rowb + (unsigned)sch * 16u));
+                vreg[i] = *reinterpret_cast<const u16x8_t*>(vbase + ((unsigned)key * v_rowb + (unsigned)sch * 16u));
             } else {
                 kreg[i] = zero8;
                 vreg[i] = zero8;
@@ -148,11 +153,28 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
         if constexpr (HAS_BIAS) {
             if (tid < ATT_BN) {
                 const int kk = t * ATT_BN + tid;
-                breg = kk < a.Nk ? bp[kk] * 1.4426950408889634f : -INFINITY;
+                breg = kk < a.Nk ? bp[kk] : -INFINITY;
             }
         }
     };
-    auto stage_write = [&](int buf) {
+    // Full tiles of the unpadded head dims: no bounds checks; one running byte offset per tensor, the NSTAGE staged
+    // rows of a thread sit at uniform distances (SROWS rows) that fold into the scalar base.
+    unsigned koff = (unsigned)(ATT_BN + srow) * k_rowb + (unsigned)sch * 16u;   // tile 1: tile 0 goes through stage_load
+    unsigned voff = (unsigned)(ATT_BN + srow) * v_rowb + (unsigned)sch * 16u;
+    const unsigned k_step = (unsigned)ATT_BN * k_rowb, v_step = (unsigned)ATT_BN * v_rowb;
+    auto stage_load_full = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            kreg[i] = *reinterpret_cast<const u16x8_t*>(kbase + (size_t)(i * SROWS) * k_rowb + koff);
+            vreg[i] = *reinterpret_cast<const u16x8_t*>(vbase + (size_t)(i * SROWS) * v_rowb + voff);
+        }
+        koff += k_step;
+        voff += v_step;
+        if constexpr (HAS_BIAS) {
+            if (tid < ATT_BN) breg = bp[t * ATT_BN + tid];
+        }
+    };
+    auto stage_write = [&](int buf) __attribute__((always_inline)) {
         unsigned char* base = smem + buf * (2 * ATT_TILE_ELEMS * 2);
 #pragma unroll
         for (int i = 0; i < NSTAGE; ++i) {
@@ -160,7 +182,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
             *reinterpret_cast<u16x8_t*>(base + ATT_TILE_ELEMS * 2 + v_woff[i]) = vreg[i];
         }
         if constexpr (HAS_BIAS) {
-            if (tid < ATT_BN) bias_lds[buf * ATT_BN + tid] = breg;
+            if (tid < ATT_BN) bias_lds[buf * ATT_BN + tid] = breg * 1.4426950408889634f;   // exp2 units
         }
     };
 
@@ -190,10 +212,18 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
 
     // One key tile.  MASKED is a compile-time tag so that the -inf masking of a ragged last tile costs nothing in the
     // other iterations (the runtime form compiled to 31 v_cndmask per tile).
-    auto tile = [&](int t, auto masked_tag) {
+    // BUF (the LDS buffer this tile reads) is a compile-time tag too: the tile loop is unrolled by two so that every
+    // ds_read / ds_write address is a per-lane register plus an immediate.
+    auto tile = [&](int t, auto masked_tag, auto buf_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const int buf = t & 1;
-        if (t + 1 < nt) stage_load(t + 1);
+        constexpr int BUFC = decltype(buf_tag)::value;   // -1: run-time parity (the wide head dims, register-bound)
+        const int buf = BUFC >= 0 ? BUFC : (t & 1);
+        if constexpr (!PAD) {
+            if (t + 1 < nfull) stage_load_full(t + 1);
+            else if (t + 1 < nt) stage_load(t + 1);
+        } else {
+            if (t + 1 < nt) stage_load(t + 1);
+        }
 
         const unsigned char* kt = smem + buf * (2 * ATT_TILE_ELEMS * 2);
         const unsigned char* vt = kt + ATT_TILE_ELEMS * 2;
@@ -256,7 +286,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
         // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two scores per VALU instruction
         const f32x2_t c2 = {HAS_BIAS ? 1.0f : a.c, HAS_BIAS ? 1.0f : a.c};
         const f32x2_t nmc2 = {-mc, -mc};
-        f32x2_t lsum2 = {0.f, 0.f};
+        f32x2_t lsum2[2] = {{0.f, 0.f}, {0.f, 0.f}};   // two chains: no dependent back-to-back packed adds
         u16x8_t pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -265,11 +295,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
                 f32x2_t x = {sacc[kb][r], sacc[kb][r + 1]};
                 x = x * c2 + nmc2;
                 f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                lsum2 += p;
+                lsum2[(r >> 1) & 1] += p;
                 pf[kb][r >> 3][r & 7] = Cvt<DT>::from_f32(p[0]);
                 pf[kb][r >> 3][(r & 7) + 1] = Cvt<DT>::from_f32(p[1]);
             }
-        l_run += lsum2[0] + lsum2[1];
+        lsum2[0] += lsum2[1];
+        l_run += lsum2[0][0] + lsum2[0][1];
 
         // ---- O^T += V^T P^T : A operand element j of lane half hh is key 16 s2 + 8 (j>>2) + 4 hh + (j&3)
 #pragma unroll
@@ -296,10 +327,25 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
         __syncthreads();
     };
 
-    const bool ragged = (a.Nk & (ATT_BN - 1)) != 0;
-    const int nfull = ragged ? nt - 1 : nt;
-    for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
-    if (ragged) tile(nt - 1, std::true_type{});
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using BR = std::integral_constant<int, -1>;
+    if constexpr (DP == 64) {
+        int t = 0;
+        for (; t + 1 < nfull; t += 2) {
+            tile(t, std::false_type{}, B0{});
+            tile(t + 1, std::false_type{}, B1{});
+        }
+        if (t < nfull) {
+            tile(t, std::false_type{}, B0{});
+            if (ragged) tile(nt - 1, std::true_type{}, B1{});
+        } else if (ragged) {
+            tile(nt - 1, std::true_type{}, B0{});
+        }
+    } else {
+        for (int t = 0; t < nfull; ++t) tile(t, std::false_type{}, BR{});
+        if (ragged) tile(nt - 1, std::true_type{}, BR{});
+    }
 
     // ---- epilogue: normalise and store (lane owns row qrow; 4 consecutive dims per 8-byte store)
     const float l_tot = xhalf_sum(l_run);
@@ -341,6 +387,8 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
         if (st[i] < 0 || (st[i] & 7) != 0) return PGN_ERR_INVALID;
     if (!pgn_aligned(q, 16) || !pgn_aligned(k, 16) || !pgn_aligned(v, 16) || !pgn_aligned(out, 16)) return PGN_ERR_INVALID;
     if (key_bias != nullptr && bias_sb < 0) return PGN_ERR_INVALID;
+    // the kernel addresses a (batch, head) key / value slice with 32-bit byte offsets
+    if (((int64_t)Nk + 2 * ATT_BN) * (k_sn > v_sn ? k_sn : v_sn) * 2 >= (int64_t)1 << 32) return PGN_ERR_UNSUPPORTED;
     // Geometry: 4 waves x 32 rows, two workgroups per CU (2 waves per SIMD from DIFFERENT workgroups, so one
     // workgroup's barrier / prologue / epilogue hides behind the other's main loop).  Measured on MI355X at every
     // SDXL shape (scripts/bench_kernels.py): 4 waves beat the 8-wave 256-row geometry by 4 % (self, N 4096) to
