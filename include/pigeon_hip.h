@@ -189,6 +189,21 @@ int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, in
 int pgn_geglu(const void* h, void* y, int dtype, int64_t M, int D, int64_t ld_h, int64_t ld_y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Convolution bias add, optionally fused with a residual add:  y = round(round(x + bias[c]) + residual).
+ * Replaces the broadcast bias add that follows every bias-less MIOpen convolution of diffusers 0.27.2
+ * ResnetBlock2D / Downsample2D / Upsample2D / conv_in (`self.conv2(hidden_states)`), and ResnetBlock2D.forward's
+ * `output_tensor = input_tensor + hidden_states` (reached through `self.unet(...)` at lavit_for_pigeon.py:752-757 and
+ * `self.vae.decode(...)` at :774): two torch launches (a strided broadcast add_ and an add, 5 tensor passes) become
+ * one (3 passes).  Same two roundings as the torch pair.
+ * x, residual (or NULL), y: [rows][C][inner] in memory order, bf16 / f16, 16-byte aligned; inner = 1 for channels-last
+ * activations (C % 8 == 0, bias 16-byte aligned), inner = H*W for NCHW (inner % 8 == 0).  bias: [C] of bias_dtype.
+ * y may alias x.
+ * Algorithmic bytes: rows*C*inner*sizeof(elem) * (3 with residual, 2 without).
+ */
+int pgn_bias_residual_add(const void* x, const void* residual, const void* bias, int bias_dtype, void* y, int dtype,
+                          int64_t rows, int C, int64_t inner, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * (residual add +) LayerNorm over the last dimension, one pass.
  * Replaces the `attn(...) + hidden_states` / `ff(...) + hidden_states` adds of diffusers 0.27.2
  * BasicTransformerBlock.forward together with the norm1/norm2/norm3 LayerNorm that consumes each sum

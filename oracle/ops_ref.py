@@ -165,3 +165,12 @@ def add_layer_norm_ref(x: torch.Tensor, residual: Optional[torch.Tensor], weight
     b = None if bias is None else bias.float()
     y32 = F.layer_norm(s.float(), (s.shape[-1],), w, b, eps)
     return s, y32.to(x.dtype), y32
+
+
+def bias_residual_add_ref(x: torch.Tensor, bias: torch.Tensor, residual=None) -> torch.Tensor:
+    """What torch does after a bias-less convolution inside diffusers ResnetBlock2D: a broadcast bias add rounded to
+    the activation dtype, then `input_tensor + hidden_states` rounded again.  x: [N, C, H, W]."""
+    y = (x.float() + bias.float().view(1, -1, 1, 1)).to(x.dtype)
+    if residual is not None:
+        y = (y.float() + residual.float()).to(x.dtype)
+    return y

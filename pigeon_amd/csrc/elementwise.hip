@@ -66,6 +66,76 @@ __device__ __forceinline__ float ld_param(const void* p, int adt, int c) {
     return adt == PGN_BF16 ? Cvt<PGN_BF16>::to_f32(hh) : Cvt<PGN_F16>::to_f32(hh);
 }
 
+// ---- convolution bias (+ residual) add -----------------------------------------------------------
+// y = round(round(x + bias[c]) + res): the two roundings torch makes when a convolution's bias is a separate
+// broadcast add (MIOpen convolutions carry no bias epilogue) followed by ResnetBlock2D's `input_tensor + hidden`.
+// Memory is [rows][C][inner]: inner = 1 for channels-last activations, inner = H*W for NCHW.
+__device__ __forceinline__ void ld_param8(const void* p, int adt, int c, float (&b)[8]) {
+    // eight consecutive parameters starting at a multiple of 8: one or two 16-byte loads
+    if (adt == PGN_F32) {
+        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p) + c);
+        const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p) + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { b[j] = lo[j]; b[4 + j] = hi[j]; }
+    } else {
+        const u16x8_t v = *reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(p) + c);
+        if (adt == PGN_BF16) unpack8<PGN_BF16>(v, b);
+        else unpack8<PGN_F16>(v, b);
+    }
+}
+
+template <int DT, bool HAS_RES>
+__device__ __forceinline__ void bias_res_8(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
+                                           unsigned short* __restrict__ y, long long i8, const float (&b)[8]) {
+    float f[8];
+    unpack8<DT>(*reinterpret_cast<const u16x8_t*>(x + i8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[j] + b[j]));
+    if constexpr (HAS_RES) {
+        float r[8];
+        unpack8<DT>(*reinterpret_cast<const u16x8_t*>(res + i8), r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += r[j];
+    }
+    *reinterpret_cast<u16x8_t*>(y + i8) = pack8<DT>(f);
+}
+
+// channels-last memory [rows][C]: a lane's 8 elements are 8 consecutive channels; the channel index advances by a
+// constant per grid-stride step (no division in the loop)
+template <int DT, bool HAS_RES>
+__global__ __launch_bounds__(EW_THREADS) void pgn_bias_res_cl_kernel(const unsigned short* __restrict__ x,
+                                                                     const unsigned short* __restrict__ res,
+                                                                     const void* __restrict__ bias, int bdt,
+                                                                     unsigned short* __restrict__ y, long long total8,
+                                                                     int C) {
+    const long long step = (long long)gridDim.x * EW_THREADS;
+    long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x;
+    int c = (int)((8 * i) % C);
+    const int cstep = (int)((8 * step) % C);
+    for (; i < total8; i += step) {
+        float b[8];
+        ld_param8(bias, bdt, c, b);
+        bias_res_8<DT, HAS_RES>(x, res, y, 8 * i, b);
+        c += cstep;
+        if (c >= C) c -= C;
+    }
+}
+
+// NCHW memory [rows*C planes][inner]: blockIdx.y walks the planes, one bias value per plane
+template <int DT, bool HAS_RES>
+__global__ __launch_bounds__(EW_THREADS) void pgn_bias_res_nchw_kernel(const unsigned short* __restrict__ x,
+                                                                       const unsigned short* __restrict__ res,
+                                                                       const void* __restrict__ bias, int bdt,
+                                                                       unsigned short* __restrict__ y, long long planes,
+                                                                       int C, long long inner8) {
+    for (long long pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+        const float bb = ld_param(bias, bdt, (int)(pl % C));
+        const float b[8] = {bb, bb, bb, bb, bb, bb, bb, bb};
+        for (long long j = (long long)blockIdx.x * EW_THREADS + threadIdx.x; j < inner8; j += (long long)gridDim.x * EW_THREADS)
+            bias_res_8<DT, HAS_RES>(x, res, y, 8 * (pl * inner8 + j), b);
+    }
+}
+
 // One wavefront per row, R vectors of 8 elements per lane held in registers (C <= 512 * R).
 template <int DT, int R, bool HAS_RES>
 __global__ __launch_bounds__(EW_THREADS) void pgn_add_layernorm_kernel(
@@ -253,6 +323,47 @@ extern "C" int pgn_image_to_uint8(const void* x, int x_dtype, void* y, int N, in
     else if (x_dtype == PGN_F16) PGN_U8(PGN_F16);
     else PGN_U8(PGN_F32);
 #undef PGN_U8
+    PGN_LAUNCH_CHECK();
+    return PGN_OK;
+}
+
+extern "C" int pgn_bias_residual_add(const void* x, const void* residual, const void* bias, int bias_dtype, void* y,
+                                     int dtype, int64_t rows, int C, int64_t inner, void* stream) {
+    if (x == nullptr || bias == nullptr || y == nullptr) return PGN_ERR_INVALID;
+    if (rows <= 0 || C <= 0 || inner <= 0 || pgn_dtype_size(bias_dtype) == 0) return PGN_ERR_INVALID;
+    if (dtype != PGN_BF16 && dtype != PGN_F16) return PGN_ERR_UNSUPPORTED;
+    // eight consecutive elements per lane: all inside one channel row (inner == 1) or one channel (inner % 8 == 0)
+    if (inner == 1 ? (C % 8) != 0 : (inner % 8) != 0) return PGN_ERR_UNSUPPORTED;
+    if (!pgn_aligned(x, 16) || !pgn_aligned(y, 16) || (residual != nullptr && !pgn_aligned(residual, 16))) return PGN_ERR_INVALID;
+    if (inner == 1 && !pgn_aligned(bias, 16)) return PGN_ERR_INVALID;   // 16-byte bias vector loads
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 block(EW_THREADS);
+    dim3 grid;
+    const long long total8 = (long long)rows * C * inner / 8, planes = (long long)rows * C, inner8 = inner / 8;
+    if (inner == 1) {
+        long long blocks = (total8 + EW_THREADS - 1) / EW_THREADS;
+        grid = dim3((unsigned)(blocks > 256LL * 32 ? 256LL * 32 : blocks));
+    } else {
+        long long bx = (inner8 + EW_THREADS - 1) / EW_THREADS;
+        if (bx > 64) bx = 64;
+        grid = dim3((unsigned)bx, (unsigned)(planes > 65535 ? 65535 : planes));
+    }
+#define PGN_BR_D(DT)                                                                                                  \
+    do {                                                                                                              \
+        const unsigned short* xs = (const unsigned short*)x;                                                          \
+        const unsigned short* rs = (const unsigned short*)residual;                                                   \
+        unsigned short* ys = (unsigned short*)y;                                                                      \
+        if (inner == 1) {                                                                                             \
+            if (residual) hipLaunchKernelGGL((pgn_bias_res_cl_kernel<DT, true>), grid, block, 0, s, xs, rs, bias, bias_dtype, ys, total8, C);   \
+            else hipLaunchKernelGGL((pgn_bias_res_cl_kernel<DT, false>), grid, block, 0, s, xs, rs, bias, bias_dtype, ys, total8, C);           \
+        } else {                                                                                                      \
+            if (residual) hipLaunchKernelGGL((pgn_bias_res_nchw_kernel<DT, true>), grid, block, 0, s, xs, rs, bias, bias_dtype, ys, planes, C, inner8); \
+            else hipLaunchKernelGGL((pgn_bias_res_nchw_kernel<DT, false>), grid, block, 0, s, xs, rs, bias, bias_dtype, ys, planes, C, inner8);        \
+        }                                                                                                             \
+    } while (0)
+    if (dtype == PGN_BF16) PGN_BR_D(PGN_BF16);
+    else PGN_BR_D(PGN_F16);
+#undef PGN_BR_D
     PGN_LAUNCH_CHECK();
     return PGN_OK;
 }

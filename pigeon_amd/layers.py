@@ -1,5 +1,6 @@
 """Building blocks shared by the UNet and the VAE decoder (state-dict names follow diffusers 0.27.2)."""
 import math
+import os
 from typing import Optional
 
 import torch
@@ -52,6 +53,33 @@ class TimestepEmbedding(nn.Module):
         return self.linear_2(F.silu(self.linear_1(sample)))
 
 
+def _conv_nobias(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+# A/B switch for measurements (scripts/): PGN_FUSE_CONV_BIAS=0 leaves every bias / residual add to torch
+FUSE_CONV_BIAS = os.environ.get("PGN_FUSE_CONV_BIAS", "1") != "0"
+
+
+def _bias_fusable(conv: nn.Conv2d, x: torch.Tensor) -> bool:
+    """MIOpen convolutions have no bias epilogue: torch adds the bias in a second, strided-broadcast launch.  When the
+    output shape allows 8-element vectors (always, except the 3/4-channel conv_out layers) the HIP kernel does it."""
+    return (FUSE_CONV_BIAS and conv.bias is not None and x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float16)
+            and conv.out_channels % 8 == 0)
+
+
+def conv2d_bias(conv: nn.Conv2d, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv(x) [+ residual] with the bias (and the residual) added by ops.bias_residual_add in one launch."""
+    if not _bias_fusable(conv, x):
+        y = conv(x)
+        return y if residual is None else y + residual
+    y = _conv_nobias(conv, x)
+    if not (y.is_contiguous(memory_format=torch.channels_last) or (y.is_contiguous() and (y.shape[2] * y.shape[3]) % 8 == 0)):
+        y = y + conv.bias.view(1, -1, 1, 1)
+        return y if residual is None else y + residual
+    return ops.bias_residual_add(y, conv.bias, residual)
+
+
 class ResnetBlock2D(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, temb_channels: Optional[int], groups: int = 32,
                  eps: float = 1e-5, output_scale_factor: float = 1.0):
@@ -65,14 +93,33 @@ class ResnetBlock2D(nn.Module):
         self.output_scale_factor = output_scale_factor
 
     def forward(self, input_tensor, temb=None):
-        h = self.conv1(self.norm1(input_tensor))
+        """diffusers ResnetBlock2D.forward.  Three broadcast / tensor adds never run as launches of their own:
+        conv1's bias and the time-embedding projection travel as ONE per-(sample, channel) vector into norm2's
+        kernel; conv2's bias (+ the shortcut's) and the residual add are one pgn_bias_residual_add launch."""
+        x = self.norm1(input_tensor)
         t = None
         if self.time_emb_proj is not None and temb is not None:
             t = self.time_emb_proj(F.silu(temb))   # [N, C]: its broadcast add is fused into norm2's kernel
-        h = self.conv2(self.norm2(h, add_nc=t))
-        if self.conv_shortcut is not None:
-            input_tensor = self.conv_shortcut(input_tensor)
-        out = input_tensor + h
+        if t is not None and _bias_fusable(self.conv1, x):
+            h = _conv_nobias(self.conv1, x)
+            t = t.float() + self.conv1.bias.float()
+        else:
+            h = conv2d_bias(self.conv1, x)
+        h = self.norm2(h, add_nc=t)
+        if self.conv_shortcut is None:
+            out = conv2d_bias(self.conv2, h, input_tensor)
+        elif _bias_fusable(self.conv2, h):
+            # both biases in one vector: shortcut(x) + b_s + conv2(h) + b_2
+            sc = _conv_nobias(self.conv_shortcut, input_tensor)
+            hh = _conv_nobias(self.conv2, h)
+            if hh.stride() == sc.stride() and (hh.is_contiguous(memory_format=torch.channels_last)
+                                               or (hh.is_contiguous() and (hh.shape[2] * hh.shape[3]) % 8 == 0)):
+                b = (self.conv2.bias.float() + self.conv_shortcut.bias.float()).to(hh.dtype)
+                out = ops.bias_residual_add(hh, b, sc)
+            else:
+                out = (sc + self.conv_shortcut.bias.view(1, -1, 1, 1)) + (hh + self.conv2.bias.view(1, -1, 1, 1))
+        else:
+            out = self.conv_shortcut(input_tensor) + self.conv2(h)
         return out if self.output_scale_factor == 1.0 else out / self.output_scale_factor
 
 
@@ -85,7 +132,7 @@ class Downsample2D(nn.Module):
     def forward(self, x):
         if self.padding == 0:
             x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
-        return self.conv(x)
+        return conv2d_bias(self.conv, x)
 
 
 class Upsample2D(nn.Module):
@@ -98,4 +145,4 @@ class Upsample2D(nn.Module):
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         else:
             x = F.interpolate(x, size=output_size, mode="nearest")
-        return self.conv(x)
+        return conv2d_bias(self.conv, x)

@@ -312,6 +312,40 @@ def geglu(h: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def bias_residual_add(x: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                      inplace: bool = True) -> torch.Tensor:
+    """x + bias[c] (+ residual) for a [N, C, H, W] activation in NCHW or channels_last memory, one launch.
+    `x` is overwritten unless inplace=False (it is the fresh output of a bias-less convolution)."""
+    lib = _lib.load()
+    _dev(x, bias, residual)
+    if x.dim() != 4:
+        raise ValueError("bias_residual_add expects [N, C, H, W]")
+    N, C, H, W = x.shape
+    if x.is_contiguous():
+        rows, inner = N, H * W
+    elif x.is_contiguous(memory_format=torch.channels_last):
+        rows, inner = N * H * W, 1
+    else:
+        raise ValueError("bias_residual_add: x must be NCHW- or channels_last-contiguous")
+    if residual is not None:
+        if residual.shape != x.shape or residual.dtype != x.dtype:
+            raise ValueError("residual must match x")
+        if residual.stride() != x.stride():
+            residual = residual.contiguous(memory_format=torch.channels_last if inner == 1 else torch.contiguous_format)
+    if bias.numel() != C:
+        raise ValueError("bias must be [C]")
+    bias = bias.contiguous()
+    y = x if inplace else torch.empty_like(x)
+
+    def run():
+        rc = lib.pgn_bias_residual_add(_ptr(x), _ptr(residual), _ptr(bias), _dt(bias), _ptr(y), _dt(x), rows, C, inner,
+                                       _stream())
+        _lib.check(rc, "pgn_bias_residual_add")
+
+    _launch("bias_residual", float(x.numel() * x.element_size() * (3 if residual is not None else 2)), run)
+    return y
+
+
 def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: Optional[torch.Tensor],
                    bias: Optional[torch.Tensor], eps: float = 1e-5):
     """LayerNorm over the last dim of (x + residual).  Returns (sum, normed); sum is x itself when residual is None."""

@@ -21,7 +21,8 @@ import torch.nn as nn
 
 from . import ops
 from .attention_processor import Attention, HipAttnProcessor
-from .layers import (Downsample2D, GroupNormAct, ResnetBlock2D, TimestepEmbedding, Upsample2D, timestep_embedding)
+from .layers import (Downsample2D, GroupNormAct, ResnetBlock2D, TimestepEmbedding, Upsample2D, conv2d_bias,
+                     timestep_embedding)
 
 
 class _Config(dict):
@@ -394,7 +395,7 @@ class UNet2DConditionModel(nn.Module):
         sample = sample.to(dtype)
         if getattr(self, "channels_last", False):
             sample = sample.contiguous(memory_format=torch.channels_last)
-        sample = self.conv_in(sample)
+        sample = conv2d_bias(self.conv_in, sample)
         res_samples = (sample,)
         for block in self.down_blocks:
             sample, outs = block(sample, emb, encoder_hidden_states, encoder_attention_mask)

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .attention_processor import Attention, TorchSdpaAttnProcessor
-from .layers import GroupNormAct, ResnetBlock2D, Upsample2D
+from .layers import GroupNormAct, ResnetBlock2D, Upsample2D, conv2d_bias
 
 
 class _Config(dict):
@@ -78,7 +78,7 @@ class Decoder(nn.Module):
         self.conv_out = nn.Conv2d(rev[-1], out_channels, 3, padding=1)
 
     def forward(self, z):
-        x = self.mid_block(self.conv_in(z))
+        x = self.mid_block(conv2d_bias(self.conv_in, z))
         for b in self.up_blocks:
             x = b(x)
         return self.conv_out(self.conv_norm_out(x))

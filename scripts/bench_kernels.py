@@ -44,6 +44,15 @@ for C, HW in ((320, 16384), (640, 16384), (960, 16384), (640, 4096), (1280, 4096
         gn = torch.nn.GroupNorm(32, C).to(dev).bfloat16()
         t2 = timeit(lambda: torch.nn.functional.silu(gn(x)), iters=5, warm=2)
         res.append((f"  torch_gn_silu_{C}x{HW}", t2 * 1e6, x.numel() * 4 / t2 / 1e9, "GB/s"))
+for C, HW in ((320, 16384), (640, 4096), (1280, 1024)):
+    side = int(HW ** 0.5)
+    x = torch.randn(Bp, C, side, side, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    r = torch.randn_like(x); b = torch.randn(C, device=dev).bfloat16()
+    t = timeit(lambda: ops.bias_residual_add(x, b, r))
+    res.append((f"bias_residual_nhwc_{C}x{HW}", t * 1e6, x.numel() * 6 / t / 1e9, "GB/s"))
+    xn = x.contiguous(); rn = r.contiguous()
+    t = timeit(lambda: ops.bias_residual_add(xn, b, rn))
+    res.append((f"bias_residual_nchw_{C}x{HW}", t * 1e6, x.numel() * 6 / t / 1e9, "GB/s"))
 for B in (16, 128):
     npred = torch.randn(2 * B, 4, 128, 128, device=dev).bfloat16(); lat = torch.randn(B, 4, 128, 128, device=dev)
     t = timeit(lambda: ops.cfg_ddim_step(npred, lat, 7.0, 0.9, 0.43, 0.92, 0.39))

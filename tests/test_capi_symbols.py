@@ -67,6 +67,10 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 1, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 1, p16, 8, None) == -1
     assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 0, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 1, p16, 1 << 20, None) == -2
     # row kernels: nulls -> invalid; D / C not a multiple of 8, fp32 io, C > 4096 -> unsupported
+    assert lib.pgn_bias_residual_add(p16, None, p16, 1, p16, 1, 2, 12, 1, None) == -2      # C % 8 with inner 1
+    assert lib.pgn_bias_residual_add(p16, None, p16, 1, p16, 1, 2, 8, 9, None) == -2       # inner % 8
+    assert lib.pgn_bias_residual_add(p16, None, None, 1, p16, 1, 2, 8, 1, None) == -1
+    assert lib.pgn_bias_residual_add(p16, None, p16, 1, p16, 0, 2, 8, 1, None) == -2       # fp32 activations
     assert lib.pgn_geglu(None, None, 1, 4, 8, 16, 8, None) == -1
     assert lib.pgn_geglu(p16, p16, 1, 4, 12, 24, 12, None) == -2
     assert lib.pgn_geglu(p16, p16, 0, 4, 8, 16, 8, None) == -2

@@ -495,3 +495,35 @@ def test_groupnorm_channels_last_matches_oracle(ops, case):
     assert (got.cpu() != want).float().mean().item() < 0.02
     again = ops.group_norm_silu(xd, 32, w.to(DEV), b.to(DEV), eps, silu, add_nc=None if t is None else t.to(DEV))
     assert torch.equal(got, again)     # no atomics: run-to-run bit-identical
+
+
+@pytest.mark.parametrize("shape", [(2, 320, 16, 24), (3, 64, 5, 7), (1, 1280, 8, 8), (2, 8, 1, 3)])
+@pytest.mark.parametrize("with_res", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_bias_residual_add_is_bit_exact_in_both_layouts(ops, shape, with_res, dtype):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * 3).to(dtype)
+    res = (torch.randn(*shape, generator=g) * 3).to(dtype) if with_res else None
+    for bdt in (dtype, torch.float32):
+        bias = torch.randn(shape[1], generator=g).to(bdt)
+        want = ops_ref.bias_residual_add_ref(x, bias, res)
+        # channels_last memory (inner = 1)
+        xc = x.to(DEV).contiguous(memory_format=torch.channels_last)
+        rc = None if res is None else res.to(DEV).contiguous(memory_format=torch.channels_last)
+        got = ops.bias_residual_add(xc, bias.to(DEV), rc, inplace=False)
+        assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got.cpu(), want)
+        if (shape[2] * shape[3]) % 8 == 0:     # NCHW memory (inner = H*W)
+            got = ops.bias_residual_add(x.to(DEV), bias.to(DEV), None if res is None else res.to(DEV), inplace=False)
+            assert torch.equal(got.cpu(), want)
+    # in place by default: the convolution output is overwritten
+    xi = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    out = ops.bias_residual_add(xi, bias.to(DEV), None)
+    assert out.data_ptr() == xi.data_ptr()
+
+
+def test_bias_residual_add_rejects_unvectorisable_shapes(ops):
+    x = torch.zeros(1, 4, 3, 3, device=DEV, dtype=torch.bfloat16)     # NCHW with H*W % 8 != 0
+    with pytest.raises(NotImplementedError):
+        ops.bias_residual_add(x, torch.zeros(4, device=DEV, dtype=torch.bfloat16))
+    with pytest.raises(ValueError):
+        ops.bias_residual_add(x[:, :, :, :2], torch.zeros(4, device=DEV, dtype=torch.bfloat16))
