@@ -189,6 +189,22 @@ int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, in
 int pgn_geglu(const void* h, void* y, int dtype, int64_t M, int D, int64_t ld_h, int64_t ld_y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Scoring stage: per-image target score and history score from CLIP features.
+ *   tgt_score[m]  = 100 * cos(img[m], txt[m])                          Evaluation/eval_utils.py:119-130
+ *                   (CLIPScore.calculate_clip_score, called from cal_scores.py:160-165)
+ *   hist_score[m] = mean_k 100 * cos(img[m], hist[m, k])               eval_utils.py:540-548 + the mean over the
+ *                   5 history images of cal_scores.py:178-179
+ * img_feat: [M, D] rows of img_ld elements (f32 / bf16 / f16: the image encoder's output); txt_feat: [M, D] rows of
+ * txt_ld elements or NULL (then tgt_score is not written); hist_feat: fp32 [M, n_hist, D], sample stride hist_ld, or
+ * n_hist == 0.  n_hist <= 16.  All arithmetic fp32; cos(a, b) = a.b / max(|a||b|, 1e-8) as F.cosine_similarity.
+ * These are the two per-image floats the multi-GPU all-gather carries.
+ * Algorithmic bytes: M * D * (sizeof(img) + sizeof(txt) + 4 * n_hist).
+ */
+int pgn_clip_scores(const void* img_feat, int img_dtype, int64_t img_ld, const void* txt_feat, int txt_dtype,
+                    int64_t txt_ld, const float* hist_feat, int64_t hist_ld, int n_hist, float* tgt_score,
+                    float* hist_score, int64_t M, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Convolution bias add, optionally fused with a residual add:  y = round(round(x + bias[c]) + residual).
  * Replaces the broadcast bias add that follows every bias-less MIOpen convolution of diffusers 0.27.2
  * ResnetBlock2D / Downsample2D / Upsample2D / conv_in (`self.conv2(hidden_states)`), and ResnetBlock2D.forward's

@@ -346,6 +346,43 @@ def bias_residual_add(x: torch.Tensor, bias: torch.Tensor, residual: Optional[to
     return y
 
 
+def clip_scores(image_features: torch.Tensor, text_features: Optional[torch.Tensor] = None,
+                history_features: Optional[torch.Tensor] = None):
+    """(tgt_score [M], hist_score [M]) fp32: 100*cos(image, text) and the mean over the history images of
+    100*cos(image, history) (Evaluation/eval_utils.py:119-130, 540-548; cal_scores.py:178-179).  Either may be None."""
+    lib = _lib.load()
+    _dev(image_features, text_features, history_features)
+    if image_features.dim() != 2:
+        raise ValueError("image_features must be [M, D]")
+    M, D = image_features.shape
+    img = image_features if image_features.stride(1) == 1 else image_features.contiguous()
+    txt = None
+    if text_features is not None:
+        if text_features.shape != (M, D):
+            raise ValueError("text_features must be [M, D]")
+        txt = text_features if text_features.stride(1) == 1 else text_features.contiguous()
+    hist, n_hist = None, 0
+    if history_features is not None:
+        if history_features.dim() != 3 or history_features.shape[0] != M or history_features.shape[2] != D:
+            raise ValueError("history_features must be [M, n_hist, D]")
+        hist = history_features.to(torch.float32).contiguous()
+        n_hist = hist.shape[1]
+    if txt is None and n_hist == 0:
+        raise ValueError("clip_scores needs text_features and / or history_features")
+    tgt = torch.empty(M, dtype=torch.float32, device=img.device) if txt is not None else None
+    hs = torch.empty(M, dtype=torch.float32, device=img.device) if n_hist else None
+    work = float(M * D * (img.element_size() + (txt.element_size() if txt is not None else 0) + 4 * n_hist))
+
+    def run():
+        rc = lib.pgn_clip_scores(_ptr(img), _dt(img), img.stride(0), _ptr(txt), _dt(txt) if txt is not None else 0,
+                                 txt.stride(0) if txt is not None else 0, _ptr(hist), n_hist * D, n_hist, _ptr(tgt),
+                                 _ptr(hs), M, D, _stream())
+        _lib.check(rc, "pgn_clip_scores")
+
+    _launch("clip_scores", work, run)
+    return tgt, hs
+
+
 def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: Optional[torch.Tensor],
                    bias: Optional[torch.Tensor], eps: float = 1e-5):
     """LayerNorm over the last dim of (x + residual).  Returns (sum, normed); sum is x itself when residual is None."""

@@ -1,0 +1,150 @@
+"""Scoring stage (Evaluation/cal_scores.py:144-206, eval_utils.py:112-156,521-556).
+CPU part: the score oracle against closed-form known answers, the ViT-H-14 architecture against its published size,
+the tower's host logic against the oracle, and the on-disk dict layout.  GPU part: HIP path vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scoring_ref, weights
+from oracle.models_ref import Policy
+
+TINY_VIT = dict(image_size=56, patch_size=14, width=128, layers=2, heads=2, mlp_ratio=4.0, output_dim=64)
+
+
+def _feats(M=6, K=5, D=64, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(M, D, generator=g), torch.randn(M, D, generator=g), torch.randn(M, K, D, generator=g))
+
+
+def test_score_oracle_known_answers():
+    img, txt, hist = _feats()
+    tgt, hs = scoring_ref.clip_scores_ref(img, 3.0 * img, torch.stack([img, -img, img, img, -img], dim=1) * 0.5)
+    assert torch.allclose(tgt, torch.full((6,), 100.0), atol=1e-3)              # parallel vectors, any scale
+    assert torch.allclose(hs, torch.full((6,), 20.0), atol=1e-3)                # (100 - 100 + 100 + 100 - 100) / 5
+    e = torch.eye(4)
+    tgt, _ = scoring_ref.clip_scores_ref(e[:2], e[2:], None)
+    assert torch.allclose(tgt, torch.zeros(2), atol=1e-6)                       # orthogonal
+    tgt, hs = scoring_ref.clip_scores_ref(img, txt, hist)
+    want = 100 * (img * txt).sum(-1) / (img.norm(dim=-1) * txt.norm(dim=-1))
+    assert torch.allclose(tgt, want, atol=1e-4)
+    want_h = torch.stack([100 * (img * hist[:, k]).sum(-1) / (img.norm(dim=-1) * hist[:, k].norm(dim=-1))
+                          for k in range(5)], 1).mean(1)
+    assert torch.allclose(hs, want_h, atol=1e-4)
+
+
+def test_vit_h_14_has_the_published_size_and_open_clip_names():
+    from pigeon_amd.clip_vision import VIT_H_14, CLIPVisionTransformer
+    with torch.device("meta"):
+        m = CLIPVisionTransformer(**VIT_H_14)
+    assert sum(p.numel() for p in m.parameters()) == 632_076_800               # ViT-H/14 image tower
+    keys = set(m.state_dict())
+    for k in ("conv1.weight", "class_embedding", "positional_embedding", "ln_pre.weight", "proj", "ln_post.bias",
+              "transformer.resblocks.31.attn.in_proj_weight", "transformer.resblocks.0.attn.out_proj.bias",
+              "transformer.resblocks.7.mlp.c_fc.weight", "transformer.resblocks.7.mlp.c_proj.bias",
+              "transformer.resblocks.7.ln_2.weight"):
+        assert k in keys, k
+    assert tuple(m.state_dict()["positional_embedding"].shape) == (257, 1280)
+
+
+def test_vision_tower_host_logic_matches_oracle_fp32():
+    from pigeon_amd.clip_vision import CLIPVisionTransformer
+    m = CLIPVisionTransformer(**TINY_VIT).eval()
+    sd = weights.synth_like(m, seed=17)
+    m.load_state_dict(sd)
+    x = torch.randn(3, 3, 56, 56, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        got = m(x)
+    want = scoring_ref.clip_vision_forward(Policy(torch.float32), sd, TINY_VIT["heads"], x)
+    assert got.shape == (3, 64)
+    assert torch.allclose(got, want, atol=2e-4, rtol=1e-4), (got - want).abs().max()
+
+
+def test_from_pretrained_strips_the_visual_prefix(tmp_path):
+    from pigeon_amd.clip_vision import CLIPVisionTransformer
+    m = CLIPVisionTransformer(**TINY_VIT)
+    sd = {("visual." + k): v for k, v in weights.synth_like(m, seed=2).items()}
+    sd["text_projection"] = torch.zeros(4, 4)       # the text tower's tensors are ignored
+    torch.save(sd, tmp_path / "open_clip_pytorch_model.bin")
+    got = CLIPVisionTransformer.from_pretrained(str(tmp_path / "open_clip_pytorch_model.bin"), **TINY_VIT)
+    assert torch.equal(got.state_dict()["proj"], sd["visual.proj"])
+
+
+def test_preprocess_shapes_and_normalisation():
+    from pigeon_amd.clip_vision import CLIP_MEAN, CLIP_STD, clip_preprocess
+    img = torch.full((2, 96, 64, 3), 128, dtype=torch.uint8)
+    px = clip_preprocess(img, resize_hw=(80, 80), image_size=56, dtype=torch.float32)
+    assert px.shape == (2, 3, 56, 56)
+    want = torch.tensor([(128 / 255 - m) / s for m, s in zip(CLIP_MEAN, CLIP_STD)])
+    assert torch.allclose(px[0, :, 10, 10], want, atol=1e-5)
+    with pytest.raises(ValueError):
+        clip_preprocess(img.float())
+
+
+def test_select_scores_layout_matches_cal_scores():
+    # cal_scores.py:184-204: select_scores[uid][tgt][genre][seq] = {"tgt_score": [per image], "hist_score": [...]}
+    from pigeon_amd.clip_vision import build_select_scores
+    all_res = {7: {100: {0: {}}, 101: {1: {}}}, 9: {100: {0: {}}}}          # 3 tasks in iteration order
+    nrs, nri = 2, 3
+    scores = torch.arange(3 * nrs * nri * 2, dtype=torch.float32).view(-1, 2)
+    out = build_select_scores(all_res, scores, nrs, nri)
+    assert list(out) == [7, 9] and list(out[7]) == [100, 101]
+    rec = out[7][101][1][1]                    # task 1, sequence 1 -> images (1*2+1)*3 + j
+    assert rec["tgt_score"] == [float(scores[9 + j, 0]) for j in range(3)]
+    assert rec["hist_score"] == [float(scores[9 + j, 1]) for j in range(3)]
+    with pytest.raises(ValueError):
+        build_select_scores(all_res, scores[:-1], nrs, nri)
+    np.save("/tmp/_sel.npy", np.array(out))    # same container the reference writes (np.save of a dict)
+    assert np.load("/tmp/_sel.npy", allow_pickle=True).item()[9][100][0][0]["tgt_score"] == out[9][100][0][0]["tgt_score"]
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_clip_scores_kernel_matches_oracle(dtype):
+    from pigeon_amd import ops
+    for M, K, D in ((6, 5, 1024), (1, 1, 64), (130, 16, 200), (3, 0, 1024)):
+        img, txt, hist = _feats(M, max(K, 1), D, seed=M)
+        img = img.to(dtype)
+        h = hist if K else None
+        tgt, hs = ops.clip_scores(img.cuda(), txt.cuda(), None if h is None else h.cuda())
+        want_t, want_h = scoring_ref.clip_scores_ref(img, txt, h)
+        assert torch.allclose(tgt.cpu(), want_t, atol=2e-3)                  # fp32 reductions on a 100-point scale
+        if K:
+            assert torch.allclose(hs.cpu(), want_h, atol=2e-3)
+        else:
+            assert hs is None
+    tgt, hs = ops.clip_scores(img.cuda(), None, hist.cuda())
+    assert tgt is None and hs.shape == (3,)
+    with pytest.raises(ValueError):
+        ops.clip_scores(img.cuda(), None, None)
+    with pytest.raises(NotImplementedError):
+        ops.clip_scores(img.cuda(), None, torch.zeros(3, 17, 1024).cuda())   # more than 16 history images
+
+
+@pytest.mark.gpu
+def test_vision_tower_and_scorer_on_gpu_match_oracle():
+    from pigeon_amd.clip_vision import CLIPScorer, CLIPVisionTransformer, clip_preprocess
+    cfg = dict(image_size=224, patch_size=14, width=320, layers=3, heads=4, mlp_ratio=4.0, output_dim=128)  # head dim 80
+    m = CLIPVisionTransformer(**cfg)
+    sd = weights.synth_like(m, seed=23)
+    m.load_state_dict(sd)
+    scorer = CLIPScorer(m, "cuda", torch.bfloat16, batch_size=3)
+    g = torch.Generator().manual_seed(5)
+    images = torch.randint(0, 256, (5, 256, 320, 3), generator=g, dtype=torch.uint8)
+    txt = torch.randn(5, 128, generator=g)
+    hist = torch.randn(5, 5, 128, generator=g)
+    feats = scorer.encode_image(images, resize_hw=(256, 256))
+    px = clip_preprocess(images, (256, 256), 224, torch.float32)              # same preprocessing on the CPU
+    want32 = scoring_ref.clip_vision_forward(Policy(torch.float32), sd, 4, px)
+    bf = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+    want16 = scoring_ref.clip_vision_forward(Policy(torch.bfloat16), bf, 4, px.to(torch.bfloat16))
+    rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
+    e_hip, e_ref = rel(feats, want32), rel(want16, want32)
+    print(f"clip tower relL2 hip-vs-fp32 {e_hip:.4f} oracle_bf16-vs-fp32 {e_ref:.4f}")
+    assert feats.shape == (5, 128) and e_hip <= 1.5 * e_ref + 0.003 and e_hip < 0.03
+    scores = scorer.score(images, txt, hist, resize_hw=(256, 256)).cpu()
+    want_t, want_h = scoring_ref.clip_scores_ref(want32, txt, hist)
+    assert scores.shape == (5, 2)
+    assert (scores[:, 0] - want_t).abs().max() < 1.0 and (scores[:, 1] - want_h).abs().max() < 1.0   # 1 point of 100
+    only_t = scorer.score(images, txt, None, resize_hw=(256, 256)).cpu()
+    assert torch.isnan(only_t[:, 1]).all() and torch.allclose(only_t[:, 0], scores[:, 0], atol=0.2)
