@@ -195,9 +195,13 @@ class CLIPScorer:
         return torch.cat(feats, dim=0)
 
     @torch.no_grad()
-    def score(self, images_u8: torch.Tensor, text_features: Optional[torch.Tensor] = None,
+    def score(self, images_u8, text_features: Optional[torch.Tensor] = None,
               history_features: Optional[torch.Tensor] = None, resize_hw=None) -> torch.Tensor:
-        """-> fp32 [M, 2] = (tgt_score, hist_score); a column without its inputs is NaN."""
+        """-> fp32 [M, 2] = (tgt_score, hist_score); a column without its inputs is NaN.  `images_u8`: uint8
+        [M, H, W, 3] tensor, or the list of equally sized PIL images generate_image returns."""
+        if not isinstance(images_u8, torch.Tensor):
+            import numpy as np
+            images_u8 = torch.from_numpy(np.stack([np.asarray(im.convert("RGB")) for im in images_u8]))
         feats = self.encode_image(images_u8, resize_hw)
         tf = None if text_features is None else text_features.to(self.device)
         hf = None if history_features is None else history_features.to(self.device)

@@ -92,16 +92,26 @@ def generate_images(lavit, image_tokens: List[torch.Tensor], labels, uids, genre
                     all_image_paths: Optional[List[str]] = None, num_return_images: int = 1, width: int = 512,
                     height: int = 512, original_size=None, crops_coords_top_left=None, num_inference_steps: int = 25,
                     guidance_scale_for_dm: float = 7.0, generator: Optional[torch.Generator] = None,
-                    rank: int = 0, world_size: int = 1, seed: int = 123):
+                    rank: int = 0, world_size: int = 1, seed: int = 123, scorer=None, text_features=None,
+                    history_features=None):
     """inference.py:345-411 with optional rank sharding.  `lavit` is a PigeonPixelDecoder (or any object with the
     reference's generate_image signature).  Each outer batch of `batch_size*num_return_sequences` token sequences is
     split over ranks; every rank writes the JPEGs of its own samples and returns its part of `all_res`
-    (rank 0 of a single-GPU run writes `all_res_dm_scale{g}.npy` exactly as the reference does)."""
+    (rank 0 of a single-GPU run writes `all_res_dm_scale{g}.npy` exactly as the reference does).
+
+    With a `scorer` (pigeon_amd.clip_vision.CLIPScorer.score, or any callable(images, text_features [n, D] | None,
+    history_features [n, K, D] | None) -> [n, 2]) every rank scores its own images right after generating them
+    (cal_scores.py:144-203 fused into the run instead of re-reading the JPEGs); the per-image (tgt_score, hist_score)
+    rows are all-gathered once per outer batch and rank 0 writes `select_scores_dm_scale{g}.npy`
+    in cal_scores.py's layout.  `text_features` [n_tasks, D] / `history_features` [n_tasks, K, D] are per task.
+    Returns all_res, or (all_res, select_scores) when a scorer is given."""
     total_token_num = len(image_tokens)
     step_num = batch_size * num_return_sequences
     total_steps = math.ceil(total_token_num / step_num)
     total_task_num = len(uids)
     all_res: Dict = {}
+    gathered_scores: List[torch.Tensor] = []
+    per_image = num_return_sequences * num_return_images
     token_start = 0
     device = lavit.device
     lat_c = lavit.unet.config.in_channels
@@ -140,5 +150,44 @@ def generate_images(lavit, image_tokens: List[torch.Tensor], labels, uids, genre
                 suffix = "" if world_size == 1 else f".rank{rank}"
                 np.save(os.path.join(save_folder, f"all_res_dm_scale{guidance_scale_for_dm}{suffix}.npy"),
                         np.array(all_res))
+        if scorer is not None:
+            if hi > lo:
+                tf = None if text_features is None else \
+                    torch.as_tensor(text_features[start + lo:start + hi]).repeat_interleave(per_image, dim=0)
+                hf = None if history_features is None else \
+                    torch.as_tensor(history_features[start + lo:start + hi]).repeat_interleave(per_image, dim=0)
+                sc = torch.as_tensor(scorer(batch_images, tf, hf), dtype=torch.float32)
+            else:
+                sc = torch.empty(0, 2, dtype=torch.float32)
+            if world_size > 1:
+                counts = []
+                for r in range(world_size):
+                    a, b = shard_range(n_tasks, r, world_size)
+                    counts.append((b - a) * per_image)
+                dev_sc = sc.to(device) if dist.get_backend() != "gloo" else sc.cpu()
+                _, sc = all_gather_results(dev_sc.new_zeros((dev_sc.shape[0], 1)), dev_sc, counts)
+            gathered_scores.append(sc.cpu())
         token_start += batch_size * num_return_sequences
-    return all_res
+    if scorer is None:
+        return all_res
+    scores = torch.cat(gathered_scores, dim=0) if gathered_scores else torch.empty(0, 2)
+    select = select_scores_from_lists(uids, target_image_iid, genres, scores, num_return_sequences, num_return_images)
+    if save_folder is not None and rank == 0:
+        np.save(os.path.join(save_folder, f"select_scores_dm_scale{guidance_scale_for_dm}.npy"), np.array(select))
+    return all_res, select
+
+
+def select_scores_from_lists(uids, target_image_iid, genres, scores: torch.Tensor, num_return_sequences: int,
+                             num_return_images: int) -> Dict:
+    """cal_scores.py:184-204: select_scores[uid][target][genre][seq] = {"tgt_score": [per image j], "hist_score": [...]}
+    from per-image rows ordered task-major, then sequence, then image (inference.py:447-448)."""
+    if scores.shape[0] != len(uids) * num_return_sequences * num_return_images:
+        raise ValueError("scores do not cover the task list")
+    out: Dict = {}
+    for i, uid in enumerate(uids):
+        slot = out.setdefault(int(uid), {}).setdefault(int(target_image_iid[i]), {}).setdefault(int(genres[i]), {})
+        for seq in range(num_return_sequences):
+            rows = scores[(i * num_return_sequences + seq) * num_return_images:
+                          (i * num_return_sequences + seq + 1) * num_return_images]
+            slot[seq] = {"tgt_score": [float(v) for v in rows[:, 0]], "hist_score": [float(v) for v in rows[:, 1]]}
+    return out

@@ -53,6 +53,11 @@ class _FakeLavit:
         return images, None, None
 
 
+def _fake_scorer(images, text_features, history_features):
+    """(token-sum of the image mod 97, its task's text feature): depends on which image and which task row it got."""
+    return torch.tensor([[img.value[0] % 97, float(text_features[i, 0])] for i, img in enumerate(images)])
+
+
 def _inputs(n_tasks, nrs, seed=0):
     g = torch.Generator().manual_seed(seed)
     tokens = [torch.randint(32002, 48386, (int(torch.randint(5, 30, (1,), generator=g)),), generator=g)
@@ -130,6 +135,14 @@ def _rank_main(rank, world, port, tmp, n_tasks, nrs, nri, bs):
                                num_return_sequences=nrs, batch_size=bs, save_folder=os.path.join(tmp, "w2"),
                                eval_name="e", num_return_images=nri, width=64, height=64, rank=rank,
                                world_size=world, seed=123)
+        # (1b) scored run: every rank scores its own images, rows are all-gathered per outer batch, rank 0 writes the
+        #      select_scores file; the result must equal the single-rank scoring of the same images
+        _, sel = runner.generate_images(_FakeLavit(), tokens, labels, uids, genres, targets, history,
+                                        num_return_sequences=nrs, batch_size=bs, save_folder=os.path.join(tmp, "w2s"),
+                                        eval_name="e", num_return_images=nri, width=64, height=64, rank=rank,
+                                        world_size=world, seed=123, scorer=_fake_scorer,
+                                        text_features=torch.arange(n_tasks, dtype=torch.float32)[:, None])
+        torch.save(sel, os.path.join(tmp, f"sel_rank{rank}.pt"))
         # (2) padded all-gather with uneven counts: rank r contributes r+2 rows
         counts = [r + 2 for r in range(world)]
         lat = torch.full((counts[rank], 4, 2, 2), float(rank + 1))
@@ -161,5 +174,16 @@ def test_world2_gloo_sharded_run_equals_single_rank_run(tmp_path):
     one, two = _read_tree(str(tmp_path / "w1")), _read_tree(str(tmp_path / "w2"))
     assert len(one) == n_tasks * nrs * nri
     assert one == two
+    # scores: gathered select_scores of both ranks == single-rank select_scores, in cal_scores.py's layout
+    _, sel1 = runner.generate_images(_FakeLavit(), tokens, labels, uids, genres, targets, history,
+                                     num_return_sequences=nrs, batch_size=bs, save_folder=str(tmp_path / "w1s"),
+                                     eval_name="e", num_return_images=nri, width=64, height=64,
+                                     generator=torch.Generator().manual_seed(123), scorer=_fake_scorer,
+                                     text_features=torch.arange(n_tasks, dtype=torch.float32)[:, None])
+    assert torch.load(tmp_path / "sel_rank0.pt") == sel1 == torch.load(tmp_path / "sel_rank1.pt")
+    rec = sel1[uids[3]][targets[3]][genres[3]][1]
+    assert rec["hist_score"] == [3.0] * nri and rec["tgt_score"] == [float(int(tokens[3 * nrs + 1].sum()) % 97)] * nri
+    on_disk = np.load(tmp_path / "w2s" / "select_scores_dm_scale7.0.npy", allow_pickle=True).item()
+    assert on_disk == sel1
     assert os.path.exists(tmp_path / "w2" / "all_res_dm_scale7.0.rank0.npy")
     assert os.path.exists(tmp_path / "w2" / "all_res_dm_scale7.0.rank1.npy")
