@@ -22,6 +22,14 @@ class HipAttnProcessor:
         # cross-attention K/V depend only on encoder_hidden_states, which is constant over the denoising loop
         self.cache_cross_kv = cache_cross_kv
         self._kv_cache = None
+        # The reference's unconditional CFG branch conditions on ALL-ZERO embeddings (lavit_for_pigeon.py:710-711).
+        # With bias-free to_k / to_v that makes K = V = 0 for those batch rows: uniform softmax over zero values, i.e.
+        # the attention output is exactly 0 and the layer's output is exactly to_out's bias.  When the pipeline
+        # declares the first `zero_ctx_rows` batch rows to be such rows, cross-attention computes the other rows only
+        # (query / key / value projections, attention core, output projection) and writes the bias into the rest:
+        # the skipped rows are bit-identical to computing them, the others see the same arithmetic (hipBLASLt may pick
+        # another tile for the smaller M), at half the cross-attention work.
+        self.zero_ctx_rows = 0
 
     def reset_cache(self):
         self._kv_cache = None
@@ -41,6 +49,11 @@ class HipAttnProcessor:
             hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
 
         is_cross = encoder_hidden_states is not None
+        k0 = self.zero_ctx_rows
+        if (is_cross and 0 < k0 < hidden_states.shape[0] and attention_mask is None and input_ndim == 3
+                and attn.to_k.bias is None and attn.to_v.bias is None and not getattr(attn, "norm_cross", None)
+                and not attn.residual_connection and attn.rescale_output_factor == 1.0):
+            return self._cross_skip_zero_rows(attn, hidden_states, encoder_hidden_states, k0)
         query = attn.to_q(hidden_states)
         if not is_cross:
             context = hidden_states
@@ -79,6 +92,27 @@ class HipAttnProcessor:
         if attn.rescale_output_factor != 1.0:
             hidden_states = hidden_states / attn.rescale_output_factor
         return hidden_states
+
+
+    def _cross_skip_zero_rows(self, attn, hidden_states, encoder_hidden_states, k0):
+        B, N, _ = hidden_states.shape
+        query = attn.to_q(hidden_states[k0:])
+        if self.cache_cross_kv and self._kv_cache is not None and self._kv_cache[0] is encoder_hidden_states:
+            key, value = self._kv_cache[1], self._kv_cache[2]
+        else:
+            key, value = attn.to_k(encoder_hidden_states[k0:]), attn.to_v(encoder_hidden_states[k0:])
+            if self.cache_cross_kv:
+                self._kv_cache = (encoder_hidden_states, key, value)
+        o = ops.attention(query, key, value, attn.heads, attn.scale, None)
+        lin = attn.to_out[0]
+        out = torch.empty(B, N, lin.out_features, dtype=o.dtype, device=o.device)
+        if lin.bias is None:
+            out[:k0].zero_()
+            torch.mm(o.view(-1, o.shape[-1]), lin.weight.t(), out=out[k0:].view(-1, lin.out_features))
+        else:
+            out[:k0] = lin.bias
+            torch.addmm(lin.bias, o.view(-1, o.shape[-1]), lin.weight.t(), out=out[k0:].view(-1, lin.out_features))
+        return out
 
 
 class TorchSdpaAttnProcessor:

@@ -13,6 +13,8 @@ the pooled one (:710-711), CFG batch order [neg...; pos...] followed by repeat_i
 """
 from typing import Callable, List, Optional, Sequence, Tuple, Union
 
+import os
+
 import numpy as np
 import torch
 
@@ -56,6 +58,8 @@ class PigeonPixelDecoder:
         if pixel_decoding not in ("highres", "lowres"):
             raise ValueError("pixel_decoding is 'highres' or 'lowres'")
         self.pixel_decoding = pixel_decoding                       # lavit_for_pigeon.py:163
+        # cross-attention skips the all-zero unconditional rows (see HipAttnProcessor.zero_ctx_rows)
+        self.skip_zero_context = os.environ.get("PGN_SKIP_ZERO_CONTEXT", "1") != "0"
         if pixel_decoding == "lowres":
             if uncond_embeddings is None:
                 raise ValueError("pixel_decoding='lowres' needs the `uncond_embeddings` buffer "
@@ -130,13 +134,21 @@ class PigeonPixelDecoder:
 
         added_cond_kwargs = {"text_embeds": add_text_embeds, "time_ids": add_time_ids}
         host_timesteps = list(self.scheduler._host_timesteps)  # no device->host sync inside the loop
-        for i, t in enumerate(host_timesteps):
-            latent_model_input = ops.cfg_expand_scale(latents, self.unet.dtype, self.scheduler.scale_divisor(t))
-            noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=input_embeds,
-                                   added_cond_kwargs=added_cond_kwargs).sample
-            latents = self.scheduler.step_cfg(noise_pred, t, latents, guidance_scale_for_diffusion).prev_sample
-            if callback is not None:
-                callback(i, t, latents)
+        # rows [0, batch_size) of input_embeds are the all-zero unconditional embeddings built above (:710-711, :731)
+        zero_rows = batch_size if (self.skip_zero_context and hasattr(self.unet, "set_zero_context_rows")) else 0
+        if zero_rows:
+            self.unet.set_zero_context_rows(zero_rows)
+        try:
+            for i, t in enumerate(host_timesteps):
+                latent_model_input = ops.cfg_expand_scale(latents, self.unet.dtype, self.scheduler.scale_divisor(t))
+                noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=input_embeds,
+                                       added_cond_kwargs=added_cond_kwargs).sample
+                latents = self.scheduler.step_cfg(noise_pred, t, latents, guidance_scale_for_diffusion).prev_sample
+                if callback is not None:
+                    callback(i, t, latents)
+        finally:
+            if zero_rows:
+                self.unet.set_zero_context_rows(0)
 
         if output_type == "latent":
             return latents, prompt_embeds, pooled_prompt_embeds

@@ -301,8 +301,12 @@ class UNet2DConditionModel(nn.Module):
                     m.set_processor(processor[f"{n}.processor"])
                 else:
                     # one processor object per layer: processors may hold per-layer state (cross K/V cache)
-                    m.set_processor(processor if not isinstance(processor, HipAttnProcessor)
-                                    else HipAttnProcessor(processor.cache_cross_kv))
+                    if isinstance(processor, HipAttnProcessor):
+                        new = HipAttnProcessor(processor.cache_cross_kv)
+                        new.zero_ctx_rows = processor.zero_ctx_rows
+                        m.set_processor(new)
+                    else:
+                        m.set_processor(processor)
 
     def enable_xformers_memory_efficient_attention(self, attention_op=None):
         """What lavit_for_pigeon.py:202 calls; on MI355X the memory-efficient kernel is the HIP one."""
@@ -315,6 +319,15 @@ class UNet2DConditionModel(nn.Module):
         self.channels_last = enabled
         self.to(memory_format=torch.channels_last if enabled else torch.contiguous_format)
         return self
+
+    def set_zero_context_rows(self, rows: int = 0):
+        """Declare that the first `rows` batch rows of every following call carry all-zero `encoder_hidden_states`
+        (the reference's unconditional CFG half, lavit_for_pigeon.py:710-711,731): cross-attention then skips them
+        — their output is exactly to_out's bias either way (HipAttnProcessor.zero_ctx_rows).  0 switches it off."""
+        for m in self.modules():
+            if isinstance(m, Attention) and isinstance(m.processor, HipAttnProcessor):
+                m.processor.zero_ctx_rows = int(rows)
+                m.processor.reset_cache()     # cached cross K/V hold the rows of the previous mode
 
     def enable_cross_kv_cache(self, enabled: bool = True):
         for m in self.modules():

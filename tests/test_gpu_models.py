@@ -248,6 +248,35 @@ def test_generate_image_argument_errors_and_generator_path(stack):
     assert _rel(a, c)[1] > 0.5       # a different seed is a different image
 
 
+def test_zero_context_rows_shortcut_changes_nothing(stack):
+    # CFG's unconditional half conditions on all-zero embeddings (lavit_for_pigeon.py:710-711): cross-attention of
+    # those rows is exactly to_out's bias, so skipping them must leave their eps rows bit-identical and the
+    # conditional rows equal up to GEMM tile selection (smaller M in the q / out projections)
+    x, ctx, pooled, ids = _unet_inputs(4, 16, 16, seed=8)
+    ctx[:2] = 0
+    pooled[:2] = 0
+    unet = stack["pipe"].unet
+    kw = dict(encoder_hidden_states=ctx.to(DEV), added_cond_kwargs={"text_embeds": pooled.to(DEV), "time_ids": ids.to(DEV)})
+    full = unet(x.to(DEV), 500, **kw).sample
+    unet.set_zero_context_rows(2)
+    try:
+        skip = unet(x.to(DEV), 500, **kw).sample
+        unet.enable_cross_kv_cache(True)
+        skip_cached = [unet(x.to(DEV), 500, **kw).sample for _ in range(2)][1]   # second call reads the cache
+    finally:
+        unet.enable_cross_kv_cache(False)
+        unet.set_zero_context_rows(0)
+    assert torch.equal(skip[:2], full[:2])
+    assert _rel(skip[2:], full[2:])[1] < 0.02 and _rel(skip_cached, skip)[1] < 0.02
+    # and the pipeline switches it on for the loop and off afterwards
+    pipe = stack["pipe"]
+    assert pipe.skip_zero_context
+    pipe.generate_image(image_tokens=weights.synth_tokens(1, seed=1), width=128, height=128, num_inference_steps=1,
+                        output_type="latent")
+    from pigeon_amd.attention_processor import HipAttnProcessor
+    assert all(p.zero_ctx_rows == 0 for p in unet.attn_processors.values() if isinstance(p, HipAttnProcessor))
+
+
 def test_channels_last_and_nchw_modes_agree(stack):
     # PigeonPixelDecoder keeps activations channels_last by default; the NCHW mode runs the same modules through the
     # NCHW GroupNorm kernels.  Same weights, same input: equal up to the bf16 noise floor (different conv solvers).
