@@ -20,6 +20,37 @@ _os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # if a caller turns cudnn.b
 _os.environ.setdefault("MIOPEN_LOG_LEVEL", "3")
 
 
+def tuned_points():
+    """(unet_batch, latent_h, latent_w) points whose convolutions are in the shipped find-db (manifest written by
+    scripts/tune_miopen.py next to the db).  Empty when MIOPEN_USER_DB_PATH points somewhere else."""
+    import json
+    path = _os.path.join(_os.environ.get("MIOPEN_USER_DB_PATH", _db), "tuned_points.json")
+    try:
+        with open(path) as fh:
+            return {tuple(p) for p in json.load(fh)}
+    except (OSError, ValueError):
+        return set()
+
+
+_warned = set()
+
+
+def warn_if_untuned(unet_batch: int, latent_h: int, latent_w: int):
+    """MIOpen's immediate-mode heuristic picks a ~7 ms CK instance for the SDXL 3x3 convolutions at shapes that are not
+    in the find-db (82 % of a batch-4 run, profiles/r01_batch4_untuned_kernel_stats_top.txt): say so once per shape."""
+    key = (int(unet_batch), int(latent_h), int(latent_w))
+    if key in _warned:
+        return
+    _warned.add(key)
+    pts = tuned_points()
+    if pts and key not in pts:
+        import warnings
+        warnings.warn(f"pigeon_amd: the convolutions of UNet batch {key[0]} at latent {key[1]}x{key[2]} are not in the "
+                      f"shipped MIOpen find-db (tuned: {sorted(pts)}); expect them to run several times slower until "
+                      f"`MIOPEN_USER_DB_PATH=<db dir> python scripts/tune_miopen.py --batch {key[0] // 2} --height "
+                      f"{key[1] * 8} --width {key[2] * 8}` has been run once on this machine", stacklevel=3)
+
+
 def enable_tuned_gemms(path=None):
     """Turn torch's TunableOp on in LOOK-UP mode with the GEMM table shipped in-tree (pigeon_amd/tunableop/, produced
     by scripts/tune_gemm.py): Linear layers whose (M, N, K) are in the table run the measured-fastest hipBLASLt /

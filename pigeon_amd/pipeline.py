@@ -133,6 +133,8 @@ class PigeonPixelDecoder:
         assert input_embeds.shape[0] == add_text_embeds.shape[0] == add_time_ids.shape[0] == latents.shape[0] * 2
 
         added_cond_kwargs = {"text_embeds": add_text_embeds, "time_ids": add_time_ids}
+        from . import warn_if_untuned
+        warn_if_untuned(2 * batch_size, height // 8, width // 8)
         host_timesteps = list(self.scheduler._host_timesteps)  # no device->host sync inside the loop
         # rows [0, batch_size) of input_embeds are the all-zero unconditional embeddings built above (:710-711, :731)
         zero_rows = batch_size if (self.skip_zero_context and hasattr(self.unet, "set_zero_context_rows")) else 0

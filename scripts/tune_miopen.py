@@ -44,15 +44,20 @@ def collect(args):
     pipe = synthetic.build_random_stack(dev, "bf16", seed=123)
     seen = {}
 
-    def hook(mod, inp):
-        x = inp[0]
-        key = (tuple(x.shape), tuple(mod.weight.shape), tuple(mod.stride), tuple(mod.padding), str(x.dtype)[6:],
-               x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous(), mod.bias is not None)
+    # every convolution of the stack ends in torch.nn.functional.conv2d (nn.Conv2d.forward and the bias-less calls of
+    # pigeon_amd.layers alike): record there
+    orig_conv2d = F.conv2d
+
+    def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+        pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+        key = (tuple(x.shape), tuple(weight.shape), pair(stride), pair(padding), str(x.dtype)[6:],
+               x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous(), False)
         seen.setdefault(key, 0)
         seen[key] += 1
+        return orig_conv2d(x, weight, bias, stride, padding, dilation, groups)
 
-    hooks = [m.register_forward_pre_hook(hook) for m in list(pipe.unet.modules()) + list(pipe.vae.modules())
-             if isinstance(m, torch.nn.Conv2d)]
+    F.conv2d = conv2d
+    torch.nn.functional.conv2d = conv2d
     h, w = args.height // 8, args.width // 8
     bp = 2 * args.batch
     with torch.no_grad():
@@ -101,6 +106,17 @@ def tune(args):
         print(f"[{i + 1}/{len(seen)}] x{cnt} in={xs} w={ws} s={stride} p={pad} cl={cl}: find {t_find:.1f} s, "
               f"{dt_run * 1e6:.0f} us, {fl / dt_run / 1e12:.0f} TFLOP/s", flush=True)
         del x, wgt, y
+    # manifest of tuned (UNet batch, latent h, latent w) points, read by pigeon_amd.warn_if_untuned
+    man = os.path.join(os.environ["MIOPEN_USER_DB_PATH"], "tuned_points.json")
+    pts = []
+    if os.path.exists(man):
+        with open(man) as fh:
+            pts = [tuple(p) for p in json.load(fh)]
+    pt = (2 * args.batch, args.height // 8, args.width // 8)
+    if not args.no_find and pt not in pts:
+        pts.append(pt)
+        with open(man, "w") as fh:
+            json.dump(sorted(pts), fh)
     print(f"done in {time.perf_counter() - t_all:.0f} s; db files: {os.listdir(os.environ['MIOPEN_USER_DB_PATH'])}", flush=True)
 
 

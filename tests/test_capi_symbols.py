@@ -79,3 +79,15 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.pgn_add_layernorm(p16, p16, None, p16, None, None, 1, 1, 4, 8, 1e-5, None) == -1   # residual w/o sum_out
     assert lib.pgn_add_layernorm(p16, None, None, p16, None, None, 1, 1, 4, 12, 1e-5, None) == -2
     assert lib.pgn_add_layernorm(p16, None, None, p16, None, None, 1, 1, 4, 8192, 1e-5, None) == -2
+
+
+def test_untuned_shape_warning_names_the_tuning_command(recwarn):
+    import pigeon_amd
+    pts = pigeon_amd.tuned_points()
+    assert (32, 128, 128) in pts                      # BASELINE configs[1]: batch 16 -> UNet batch 32, 1024x1024
+    pigeon_amd._warned.clear()
+    pigeon_amd.warn_if_untuned(32, 128, 128)
+    assert len(recwarn) == 0
+    pigeon_amd.warn_if_untuned(6, 24, 40)
+    pigeon_amd.warn_if_untuned(6, 24, 40)             # once per shape
+    assert len(recwarn) == 1 and "tune_miopen.py --batch 3 --height 192 --width 320" in str(recwarn[0].message)
