@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cross-kv-cache", action="store_true", help="reuse cross-attention K/V across denoising steps")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="replay the denoising loop as one hipGraph (pays when the loop is launch-bound: batch <= 2)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real path) or gloo (rehearsal)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal of the multi-rank control flow on a one-GPU box: every rank uses cuda:0 (gloo only)")
@@ -165,18 +167,28 @@ def main():
     pipe = synthetic.build_random_stack(device, "bf16", seed=123)
     if args.cross_kv_cache:
         pipe.unet.enable_cross_kv_cache(True)
+    if args.hip_graph:
+        if world > 1:
+            raise SystemExit("--hip-graph is the single-GPU small-batch latency option (no per-step callback, so no "
+                             "latents for the all-gather)")
+        pipe.enable_hip_graph(True)
     n_seq = args.batch // args.num_return_images
     tokens = [t.to(device) for t in synthetic.synthetic_tokens(n_seq, seed=123 + rank)]
     gen = torch.Generator(device=device).manual_seed(123 + rank)
     timer = LaunchTimer()
     ops.set_launch_timer(timer)
 
+    loop_marks = []   # (start, end-of-denoising-loop) event pairs of the timed steps: SURVEY 8(d) metric (i)
+
     def one_step():
+        mark = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+        last["mark"] = mark
+        mark[0].record()
         images, _, _ = pipe.generate_image(image_tokens=tokens, num_return_images=args.num_return_images,
                                            width=args.width, height=args.height,
                                            num_inference_steps=args.denoise_steps,
                                            guidance_scale_for_diffusion=args.guidance, generator=gen,
-                                           output_type="uint8", callback=keep_latents)
+                                           output_type="uint8", callback=None if args.hip_graph else keep_latents)
         host = images.cpu()   # device -> host boundary (lavit_for_pigeon.py:782), uint8 instead of fp32
         if world > 1:         # the path's one exchange step: collect final latents from every rank
             runner.all_gather_results(last["latents"], None, [args.batch] * world)
@@ -186,6 +198,9 @@ def main():
 
     def keep_latents(i, t, x):
         last["latents"] = x
+        if i == args.denoise_steps - 1:          # the loop has been enqueued: what follows is VAE decode + uint8 copy
+            last["mark"][1].record()
+            loop_marks.append(last["mark"])
 
     def fence():
         if world > 1:
@@ -196,6 +211,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     fence()
+    loop_marks.clear()
     state["phase"] = "timed steps"
     # HIP-event brackets around every C-ABI launch cost ~1 % of a step (25 k event pairs), so they are recorded during
     # the LAST timed step only: still inside the timed region, on the launch stream, at 1/K of the cost
@@ -213,6 +229,7 @@ def main():
 
     images_total = args.batch * world * args.steps
     value = images_total / elapsed
+    loop_ms = sum(a.elapsed_time(b) for a, b in loop_marks) / max(1, len(loop_marks))   # this rank, per step
     agg = timer.summary() if not args.no_kernel_timing else {}
     kernels = {}
     for kind, (n, work, secs) in agg.items():
@@ -257,6 +274,9 @@ def main():
                                    "end to end incl. VAE decode and uint8 copy to host",
                        "batch_per_gpu": args.batch, "height": args.height, "width": args.width,
                        "denoise_steps": args.denoise_steps, "parallelism": f"sample-sharded dp{world}"},
+            # embeds + denoising loop only (no VAE decode / uint8 copy), this rank's GPU time per step
+            "loop_only": {"images_per_sec_per_gpu": args.batch / (loop_ms * 1e-3) if loop_ms > 0 else None,
+                          "ms_per_step": loop_ms if loop_ms > 0 else None},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
             "attention_mfma_util_pct": None if roofline is None else 100.0 * roofline["frac"],
         }

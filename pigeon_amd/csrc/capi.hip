@@ -12,6 +12,8 @@ extern "C" const char* pgn_error_string(int code) {
 }
 
 extern "C" size_t pgn_workspace_bytes(int op) {
-    (void)op;  // no entry point needs scratch memory: every kernel works in registers / LDS
+    // Shape-independent scratch: none.  The two GroupNorm paths that reduce across workgroups size their caller-provided
+    // workspace from the shape: pgn_groupnorm_workspace_bytes / pgn_groupnorm_nhwc_workspace_bytes.
+    (void)op;
     return 0;
 }

@@ -60,6 +60,8 @@ class PigeonPixelDecoder:
         self.pixel_decoding = pixel_decoding                       # lavit_for_pigeon.py:163
         # cross-attention skips the all-zero unconditional rows (see HipAttnProcessor.zero_ctx_rows)
         self.skip_zero_context = os.environ.get("PGN_SKIP_ZERO_CONTEXT", "1") != "0"
+        self.use_hip_graph = os.environ.get("PGN_HIP_GRAPH", "0") == "1"      # see enable_hip_graph
+        self._graphs = {}
         if pixel_decoding == "lowres":
             if uncond_embeddings is None:
                 raise ValueError("pixel_decoding='lowres' needs the `uncond_embeddings` buffer "
@@ -141,13 +143,15 @@ class PigeonPixelDecoder:
         if zero_rows:
             self.unet.set_zero_context_rows(zero_rows)
         try:
-            for i, t in enumerate(host_timesteps):
-                latent_model_input = ops.cfg_expand_scale(latents, self.unet.dtype, self.scheduler.scale_divisor(t))
-                noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=input_embeds,
-                                       added_cond_kwargs=added_cond_kwargs).sample
-                latents = self.scheduler.step_cfg(noise_pred, t, latents, guidance_scale_for_diffusion).prev_sample
-                if callback is not None:
-                    callback(i, t, latents)
+            if self.use_hip_graph and callback is None:
+                latents = self._denoise_graphed(latents, input_embeds, added_cond_kwargs, host_timesteps,
+                                                guidance_scale_for_diffusion, zero_rows)
+            else:
+                for i, t in enumerate(host_timesteps):
+                    latents = self._denoise_step(latents, t, t, input_embeds, added_cond_kwargs,
+                                                 guidance_scale_for_diffusion)
+                    if callback is not None:
+                        callback(i, t, latents)
         finally:
             if zero_rows:
                 self.unet.set_zero_context_rows(0)
@@ -156,6 +160,63 @@ class PigeonPixelDecoder:
             return latents, prompt_embeds, pooled_prompt_embeds
         images = self.decode_latents(latents, output_type)
         return images, prompt_embeds, pooled_prompt_embeds
+
+    def _denoise_step(self, latents, t_host, t_unet, input_embeds, added_cond_kwargs, guidance):
+        """One iteration of :744-764: three fused launches around the UNet forward."""
+        latent_model_input = ops.cfg_expand_scale(latents, self.unet.dtype, self.scheduler.scale_divisor(t_host))
+        noise_pred = self.unet(latent_model_input, t_unet, encoder_hidden_states=input_embeds,
+                               added_cond_kwargs=added_cond_kwargs).sample
+        return self.scheduler.step_cfg(noise_pred, t_host, latents, guidance).prev_sample
+
+    # ---- HIP graph of the whole denoising loop -------------------------------------------------------------------
+    def enable_hip_graph(self, enabled: bool = True):
+        """Capture the denoising loop (all steps: ~3 k launches each) into ONE hipGraph per (batch shape, schedule,
+        guidance) and replay it.  A UNet forward takes ~34 ms of host time to enqueue; at UNet batch 32 the GPU needs
+        250 ms for it and the host is hidden, at batch 2 (one image) the GPU needs ~20 ms and the loop is launch-bound:
+        that is where the graph pays.  Off by default; per-step callbacks fall back to the eager loop."""
+        self.use_hip_graph = bool(enabled)
+        if not enabled:
+            self._graphs.clear()
+        return self
+
+    def _denoise_graphed(self, latents, input_embeds, added_cond_kwargs, host_timesteps, guidance, zero_rows):
+        key = (tuple(latents.shape), tuple(input_embeds.shape), tuple(host_timesteps), float(guidance), zero_rows,
+               type(self.scheduler).__name__)
+        entry = self._graphs.get(key)
+        if entry is None:
+            st = {"lat": latents.clone(), "emb": input_embeds.clone(),
+                  "text": added_cond_kwargs["text_embeds"].clone(), "ids": added_cond_kwargs["time_ids"].clone()}
+            added = {"text_embeds": st["text"], "time_ids": st["ids"]}
+            # timesteps as device tensors made BEFORE capture (a host->device copy cannot be captured)
+            t_dev = [torch.tensor([t], device=self.device,
+                                  dtype=torch.float32 if isinstance(t, float) else torch.int64) for t in host_timesteps]
+            # one eager iteration on a side stream first: library handles, workspaces and MIOpen / hipBLASLt solution
+            # look-ups must exist before the capture starts
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                self._denoise_step(st["lat"], host_timesteps[0], t_dev[0], st["emb"], added, guidance)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            self._reset_scheduler_cursor()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                x = st["lat"]
+                for t, td in zip(host_timesteps, t_dev):
+                    x = self._denoise_step(x, t, td, st["emb"], added, guidance)
+                st["out"] = x
+            entry = self._graphs[key] = (graph, st, t_dev)
+        graph, st, _ = entry
+        st["lat"].copy_(latents)
+        st["emb"].copy_(input_embeds)
+        st["text"].copy_(added_cond_kwargs["text_embeds"])
+        st["ids"].copy_(added_cond_kwargs["time_ids"])
+        graph.replay()
+        return st["out"].clone()
+
+    def _reset_scheduler_cursor(self):
+        # schedulers with a step cursor (Euler) advanced it during the warm-up iteration
+        if getattr(self.scheduler, "_step_index", None) is not None:
+            self.scheduler._step_index = None
 
     # ---- :822-895 ------------------------------------------------------------------------------
     @torch.no_grad()

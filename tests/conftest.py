@@ -12,6 +12,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the tiny test shapes are (deliberately) not in the shipped MIOpen find-db
+    config.addinivalue_line("filterwarnings", "ignore:pigeon_amd. the convolutions of UNet batch:UserWarning")
 
 
 @pytest.fixture(scope="session")

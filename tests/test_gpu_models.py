@@ -277,6 +277,33 @@ def test_zero_context_rows_shortcut_changes_nothing(stack):
     assert all(p.zero_ctx_rows == 0 for p in unet.attn_processors.values() if isinstance(p, HipAttnProcessor))
 
 
+def test_hip_graph_replay_equals_eager_loop(stack):
+    # enable_hip_graph(): the whole denoising loop is captured once per (shape, schedule, guidance) and replayed;
+    # same kernels, same order -> same latents as the eager loop up to the GEMMs' run-to-run noise floor
+    pipe = stack["pipe"]
+    kw = dict(width=128, height=160, num_inference_steps=3, guidance_scale_for_diffusion=7.0, output_type="latent")
+    toks_a, toks_b = weights.synth_tokens(2, seed=11), weights.synth_tokens(2, seed=12)
+    g = torch.Generator().manual_seed(5)
+    noise_a, noise_b = torch.randn(2, 4, 20, 16, generator=g), torch.randn(2, 4, 20, 16, generator=g)
+    eager_a = pipe.generate_image(image_tokens=toks_a, latents=noise_a.to(DEV), **kw)[0]
+    eager_b = pipe.generate_image(image_tokens=toks_b, latents=noise_b.to(DEV), **kw)[0]
+    pipe.enable_hip_graph(True)
+    try:
+        graph_a = pipe.generate_image(image_tokens=toks_a, latents=noise_a.to(DEV), **kw)[0]      # capture + replay
+        assert len(pipe._graphs) == 1
+        graph_b = pipe.generate_image(image_tokens=toks_b, latents=noise_b.to(DEV), **kw)[0]      # replay, new inputs
+        graph_a2 = pipe.generate_image(image_tokens=toks_a, latents=noise_a.to(DEV), **kw)[0]
+        assert len(pipe._graphs) == 1
+        steps = []
+        pipe.generate_image(image_tokens=toks_a, latents=noise_a.to(DEV), callback=lambda i, t, x: steps.append(i), **kw)
+        assert steps == [0, 1, 2]            # a per-step callback runs the eager loop
+    finally:
+        pipe.enable_hip_graph(False)
+    assert not pipe._graphs
+    assert _rel(graph_a, eager_a)[1] < 0.06 and _rel(graph_b, eager_b)[1] < 0.06 and _rel(graph_a2, graph_a)[1] < 0.06
+    assert _rel(graph_a, eager_b)[1] > 0.5   # the replay really consumed the new inputs
+
+
 def test_channels_last_and_nchw_modes_agree(stack):
     # PigeonPixelDecoder keeps activations channels_last by default; the NCHW mode runs the same modules through the
     # NCHW GroupNorm kernels.  Same weights, same input: equal up to the bf16 noise floor (different conv solvers).
