@@ -6,7 +6,7 @@
 set -e -o pipefail
 cd "$(dirname "$0")/.."
 DB=$PWD/gpurun_out/miopen_db_new
-mkdir -p $DB && cp pigeon_amd/miopen_db/*.txt $DB/
+[ -d $DB ] || { mkdir -p $DB && cp pigeon_amd/miopen_db/*.txt $DB/; }   # a second call in one gpurun keeps the first's finds
 export MIOPEN_USER_DB_PATH=$DB
 for spec in $1; do
   IFS=: read B H W <<< "$spec"
