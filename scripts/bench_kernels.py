@@ -18,7 +18,9 @@ def timeit(fn, iters=20, warm=3):
 
 res = []
 Bp = int(os.environ.get("BP", "32"))
-for name, H, Nq, Nk in (("self_L1", 10, 4096, 4096), ("self_L2", 20, 1024, 1024), ("cross_L1", 10, 4096, 256), ("cross_L2", 20, 1024, 256),
+shapes_cfg5 = (("self_L1_2x", 10, 16384, 16384), ("self_L2_2x", 20, 4096, 4096), ("cross_L1_2x_k1024", 10, 16384, 1024),
+               ("cross_L2_2x_k1024", 20, 4096, 1024))   # BASELINE configs[4]: 2x latent side, long cross-attention
+for name, H, Nq, Nk in shapes_cfg5 if os.environ.get("SHAPES") == "cfg5" else (("self_L1", 10, 4096, 4096), ("self_L2", 20, 1024, 1024), ("cross_L1", 10, 4096, 256), ("cross_L2", 20, 1024, 256),
                         ("self_L1_ragged", 10, 3952, 3952), ("self_L2_ragged", 20, 988, 988)):
     C = H * 64
     q = torch.randn(Bp, Nq, C, device=dev).bfloat16(); k = torch.randn(Bp, Nk, C, device=dev).bfloat16(); v = torch.randn(Bp, Nk, C, device=dev).bfloat16()
@@ -33,6 +35,10 @@ for name, H, Nq, Nk in (("self_L1", 10, 4096, 4096), ("self_L2", 20, 1024, 1024)
     if os.environ.get("SDPA"):
         t2 = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(tq, tk, tv), iters=5, warm=2)
         res.append((f"  torch_sdpa_{name}", t2 * 1e6, fl / t2 / 1e12, "TFLOP/s"))
+if os.environ.get("SHAPES") == "cfg5":
+    for r in res:
+        print(f"{r[0]:34s} {r[1]:10.1f} us  {r[2]:9.1f} {r[3]}")
+    sys.exit(0)
 for C, HW in ((320, 16384), (640, 16384), (960, 16384), (640, 4096), (1280, 4096), (1920, 4096), (1280, 1024), (2560, 1024)):
     x = torch.randn(Bp, C, HW, device=dev).bfloat16(); w = torch.randn(C, device=dev).bfloat16(); b = torch.randn(C, device=dev).bfloat16()
     t = timeit(lambda: ops.group_norm_silu(x, 32, w, b, 1e-5, True))

@@ -153,3 +153,38 @@ def test_config5_groupnorm_at_double_latent_side():
     x = (torch.randn(4, 320, 256, 256, device=DEV) * 1.3 - 0.4).to(torch.bfloat16)
     y = ops.group_norm_silu(x, 32, None, None, 1e-5, silu=False, out_dtype=None).float().view(4, 32, -1)
     assert y.mean(-1).abs().max().item() < 5e-3 and (y.var(-1, unbiased=False) - 1).abs().max().item() < 1e-2
+
+
+def test_config2_bias_residual_add_full_size_equals_the_torch_pair():
+    # pgn_bias_residual_add at the largest UNet activation of configs[1] ([32, 320, 128, 128], channels-last) against
+    # the two torch launches it replaces, run on the same device: bit-exact; and linear in the bias at full size
+    from pigeon_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(32, 320, 128, 128, device=DEV, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    r = torch.randn(32, 320, 128, 128, device=DEV, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(320, device=DEV, generator=g).bfloat16()
+    want = (x + b.view(1, -1, 1, 1)) + r
+    got = ops.bias_residual_add(x, b, r, inplace=False)
+    assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want)
+    assert torch.equal(ops.bias_residual_add(x, torch.zeros_like(b), None, inplace=False), x)
+
+
+def test_scoring_stage_full_size_properties():
+    # ViT-H-14 at full size (632 M parameters, random init): features are deterministic per image, independent of the
+    # batch an image is scored in, and the scores of an image against its own features are 100 / 100
+    from pigeon_amd.clip_vision import VIT_H_14, CLIPScorer, CLIPVisionTransformer
+    from pigeon_amd.synthetic import _materialize
+    with torch.device("meta"):
+        m = CLIPVisionTransformer(**VIT_H_14)
+    scorer = CLIPScorer(_materialize(m, DEV, torch.bfloat16, 5), DEV, torch.bfloat16, batch_size=8)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    images = torch.randint(0, 256, (12, 512, 512, 3), device=DEV, dtype=torch.uint8, generator=g)
+    feats = scorer.encode_image(images, resize_hw=(512, 512))
+    assert feats.shape == (12, 1024) and torch.isfinite(feats.float()).all()
+    alone = scorer.encode_image(images[5:6], resize_hw=(512, 512))
+    assert _rel(alone, feats[5:6]) < 0.03                      # batch-shape dependent GEMM tiles only
+    scores = scorer.score(images, feats.float(), feats.float()[:, None, :].repeat(1, 5, 1), resize_hw=(512, 512))
+    assert torch.allclose(scores, torch.full_like(scores, 100.0), atol=0.5)
+    other = scorer.score(images, feats.float().roll(1, 0), None, resize_hw=(512, 512))
+    # (a random-init tower maps noise images to nearly parallel features: cos ~ 0.9986, still separable from 1)
+    assert (other[:, 0] < 99.95).all() and torch.isnan(other[:, 1]).all()
