@@ -255,7 +255,10 @@ def token_decoder_forward(p: Policy, sd_in, x, token_nums, num_heads=16):
 
 
 # ---- VAE decoder (diffusers AutoencoderKL.decode; call site lavit_for_pigeon.py:774) ----------------
-def vae_decode(p: Policy, sd_in, cfg: dict, z):
+def vae_decode(p: Policy, sd_in, cfg: dict, z, upscale_policy: Optional[Policy] = None):
+    """`upscale_policy`: the dtype policy of the up blocks after `upcast_vae` (lavit_for_pigeon.py:796-813): the fp16
+    VAE is moved to fp32 except post_quant_conv / conv_in / mid_block, and diffusers' Decoder.forward casts the
+    activation to the up blocks' dtype after the mid block."""
     sd = SD(sd_in)
     g = cfg["norm_num_groups"]
     x = p.conv(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
@@ -269,6 +272,9 @@ def vae_decode(p: Policy, sd_in, cfg: dict, z):
     head_dim = cfg.get("attention_head_dim") or c
     x = attn_layer(p, a, hs, None, c // head_dim).transpose(1, 2).reshape(b, c, h, w) + x
     x = resnet(p, m.sub("resnets.1."), x, None, g, 1e-6)
+    if upscale_policy is not None:
+        p = upscale_policy
+        x = x.to(p.compute)
     i = 0
     while d.has(f"up_blocks.{i}."):
         u = d.sub(f"up_blocks.{i}.")

@@ -269,6 +269,26 @@ class PigeonPixelDecoder:
         and a 16 x 256 x 1024 x 1024 activation exceeds the 2^31-element limit of torch's nearest-upsample launch."""
         if self.vae is None:
             raise RuntimeError("no VAE attached")
+        # :766-770 — an fp16 VAE with force_upcast overflows: decode with the up blocks in fp32, cast back afterwards
+        needs_upcasting = self.vae.dtype == torch.float16 and bool(self.vae.config.get("force_upcast", False))
+        if needs_upcasting:
+            self.upcast_vae()
+        try:
+            return self._decode_latents(latents, output_type, chunk, divide_in_fp32)
+        finally:
+            if needs_upcasting:
+                self.vae.to(dtype=torch.float16)                                               # :777-778
+
+    def upcast_vae(self):
+        """lavit_for_pigeon.py:796-813: the VAE goes to fp32; with a fused attention processor (ours is one, like
+        AttnProcessor2_0 / XFormersAttnProcessor there) post_quant_conv, conv_in and the mid block return to fp16."""
+        dtype = self.vae.dtype
+        self.vae.to(dtype=torch.float32)
+        self.vae.post_quant_conv.to(dtype)
+        self.vae.decoder.conv_in.to(dtype)
+        self.vae.decoder.mid_block.to(dtype)
+
+    def _decode_latents(self, latents, output_type, chunk, divide_in_fp32):
         vae_dtype = next(iter(self.vae.post_quant_conv.parameters())).dtype
         if divide_in_fp32:
             z = (latents / self.vae.config.scaling_factor).to(vae_dtype)

@@ -79,6 +79,9 @@ class Decoder(nn.Module):
 
     def forward(self, z):
         x = self.mid_block(conv2d_bias(self.conv_in, z))
+        # diffusers Decoder.forward: `sample = sample.to(upscale_dtype)` — after upcast_vae (lavit_for_pigeon.py:796-813)
+        # conv_in / mid_block stay in fp16 while the up blocks run in fp32
+        x = x.to(next(iter(self.up_blocks.parameters())).dtype)
         for b in self.up_blocks:
             x = b(x)
         return self.conv_out(self.conv_norm_out(x))

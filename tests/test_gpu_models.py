@@ -191,6 +191,34 @@ def test_vae_decode_matches_oracle(stack):
     assert np.abs(u8.astype(int) - ref_img.astype(int)).max() <= 6   # 2 % of 255 on a bf16 decoder
 
 
+def test_fp16_vae_is_upcast_for_decoding_and_cast_back(stack):
+    # lavit_for_pigeon.py:766-778,796-813: fp16 VAE + force_upcast -> up blocks in fp32, post_quant_conv / conv_in /
+    # mid block stay fp16, everything back to fp16 afterwards
+    from pigeon_amd.pipeline import PigeonPixelDecoder
+    from pigeon_amd.vae import AutoencoderKL
+    vae = AutoencoderKL(**dict(TINY_VAE, force_upcast=True))
+    sd = weights.synth_like(vae, 5)
+    vae.load_state_dict(sd)
+    from pigeon_amd.token_decoder import HighresVQDecoder
+    from pigeon_amd.unet import UNet2DConditionModel
+    p16 = PigeonPixelDecoder(stack["codebook"], HighresVQDecoder(depth=1), UNet2DConditionModel(**TINY_UNET), vae, None,
+                             "fp16", DEV)              # own (throw-away) modules: the constructor casts in place
+    if True:
+        assert p16.vae.dtype == torch.float16
+        z = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(6))
+        seen = {}
+        hook = p16.vae.decoder.up_blocks[0].register_forward_pre_hook(lambda m, a: seen.update(dt=a[0].dtype))
+        u8 = p16.decode_latents(z.to(DEV), "uint8").cpu().numpy()
+        hook.remove()
+        assert seen["dt"] == torch.float32                                    # the up blocks ran in fp32
+        assert all(p.dtype == torch.float16 for p in p16.vae.parameters())     # and were cast back (:777-778)
+        h = lambda sd_: {k: v.to(torch.float16) for k, v in sd_.items()}
+        want = models_ref.vae_decode(Policy(torch.float16), h(sd), dict(vae.config), z.to(torch.float16) / 0.13025,
+                                     upscale_policy=Policy(torch.float32))
+        ref_img = ((want.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy() * 255).round().astype("uint8")
+        assert np.abs(u8.astype(int) - ref_img.astype(int)).max() <= 3        # fp32 up blocks: ~1 grey level
+
+
 def test_generate_image_per_step_latents_match_oracle(stack):
     pipe = stack["pipe"]
     tokens = weights.synth_tokens(2, seed=9)
