@@ -45,7 +45,8 @@ class PigeonPixelDecoder:
 
     def __init__(self, codebook: torch.Tensor, tokenizer_decoder, unet, vae, scheduler=None,
                  model_dtype: str = "bf16", device: Union[str, torch.device] = "cuda", channels_last: bool = True,
-                 pixel_decoding: str = "highres", uncond_embeddings: Optional[torch.Tensor] = None):
+                 pixel_decoding: str = "highres", uncond_embeddings: Optional[torch.Tensor] = None,
+                 safety_checker: Optional[Callable] = None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("PigeonPixelDecoder runs on an MI355X (device 'cuda:N'); there is no CPU path")
@@ -55,6 +56,9 @@ class PigeonPixelDecoder:
         self.unet = unet.to(self.device, self.dtype).eval().requires_grad_(False)
         self.vae = None if vae is None else vae.to(self.device, self.dtype).eval().requires_grad_(False)
         self.scheduler = scheduler if scheduler is not None else DDIMScheduler()
+        # check_safety (lavit_for_pigeon.py:58,206-212,784-785): callable(images float NHWC [0, 1]) -> (images, flags);
+        # the CLIP-based StableDiffusionSafetyChecker itself is outside the accelerated path (off in run_inf.sh)
+        self.safety_checker = safety_checker
         if pixel_decoding not in ("highres", "lowres"):
             raise ValueError("pixel_decoding is 'highres' or 'lowres'")
         self.pixel_decoding = pixel_decoding                       # lavit_for_pigeon.py:163
@@ -73,6 +77,37 @@ class PigeonPixelDecoder:
             for m in (self.unet, self.vae):
                 if m is not None and hasattr(m, "enable_channels_last"):
                     m.enable_channels_last(True)
+
+    @classmethod
+    def from_pretrained(cls, model_path: str, pixel_decoding: str = "highres", model_dtype: str = "bf16",
+                        device: Union[str, torch.device] = "cuda", decoder_depth: int = 12, **kwargs):
+        """Build the stack from a LaVIT checkpoint directory exactly as the reference does: codebook from
+        `visual_tokenizer/tokenizer_encoder.bin` (`quantize.embedding.weight`, modeling_visual_tokenzier.py:437-442),
+        token decoder by `build_tokenizer_decoder` (modeling_decoder.py:340-351), and the diffusion modules of
+        `prepare_dm_to_generate_image` (lavit_for_pigeon.py:166-170,185-191): `{highres_,}pixel_decoding/{vae,scheduler,
+        unet}` (+ `uncond_embeddings.bin` for the lowres decoder).  Pickle files go through weights_only loading."""
+        import os
+        from .token_decoder import build_tokenizer_decoder
+        from .unet import UNet2DConditionModel
+        from .vae import AutoencoderKL
+        dtype = torch.bfloat16 if model_dtype == "bf16" else torch.float16
+        enc_path = os.path.join(model_path, "visual_tokenizer", "tokenizer_encoder.bin")
+        try:       # the file also holds the 1 B-parameter EVA-CLIP encoder: map it, copy the 2 MiB codebook out
+            enc = torch.load(enc_path, map_location="cpu", weights_only=True, mmap=True)
+        except (RuntimeError, ValueError):     # legacy (non-zip) serialisation cannot be mapped
+            enc = torch.load(enc_path, map_location="cpu", weights_only=True)
+        codebook = enc["quantize.embedding.weight"].float().clone()
+        del enc
+        decoder = build_tokenizer_decoder(model_path, pixel_decoding=pixel_decoding, depth=decoder_depth)
+        diff_dir = os.path.join(model_path, "pixel_decoding" if pixel_decoding == "lowres" else "highres_pixel_decoding")
+        vae = AutoencoderKL.from_pretrained(diff_dir, subfolder="vae", torch_dtype=dtype)
+        scheduler = DDIMScheduler.from_pretrained(diff_dir, subfolder="scheduler")
+        unet = UNet2DConditionModel.from_pretrained(diff_dir, subfolder="unet", use_safetensors=False, torch_dtype=dtype)
+        uncond = None
+        if pixel_decoding == "lowres":
+            uncond = torch.load(os.path.join(diff_dir, "uncond_embeddings.bin"), map_location="cpu", weights_only=True)
+        return cls(codebook, decoder, unet, vae, scheduler, model_dtype, device, pixel_decoding=pixel_decoding,
+                   uncond_embeddings=uncond, **kwargs)
 
     # ---- :897-920 ------------------------------------------------------------------------------
     @torch.no_grad()
@@ -305,6 +340,16 @@ class PigeonPixelDecoder:
                 image = (image.float() / 2 + 0.5).clamp(0, 1)
             outs.append(image)
         image = torch.cat(outs, dim=0)
+        if self.safety_checker is not None:
+            # :784-785 / :815-820 — the reference hands float NHWC arrays in [0, 1] to its StableDiffusionSafetyChecker,
+            # which blacks out flagged images; here the checker is a caller-supplied callable with that contract
+            arr = image.cpu().permute(0, 2, 3, 1).numpy() if output_type == "np" else \
+                image.cpu().numpy().astype(np.float32) / 255.0
+            arr, _ = self.safety_checker(arr)
+            if output_type == "np":
+                return arr
+            u8 = torch.from_numpy((np.asarray(arr) * 255).round().astype("uint8"))
+            return u8.to(image.device) if output_type == "uint8" else numpy_to_pil(u8.numpy())
         if output_type == "np":
             return image.cpu().permute(0, 2, 3, 1).numpy()
         u8 = image

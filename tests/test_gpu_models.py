@@ -219,6 +219,68 @@ def test_fp16_vae_is_upcast_for_decoding_and_cast_back(stack):
         assert np.abs(u8.astype(int) - ref_img.astype(int)).max() <= 3        # fp32 up blocks: ~1 grey level
 
 
+def test_safety_checker_hook_gets_unit_range_arrays_and_can_black_out(stack):
+    # lavit_for_pigeon.py:784-785: images pass through the checker as float NHWC in [0, 1] before PIL conversion
+    pipe = stack["pipe"]
+    z = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(6)).to(DEV)
+    plain = pipe.decode_latents(z, "uint8").cpu().numpy()
+    seen = {}
+
+    def checker(arr):
+        seen["range"] = (float(arr.min()), float(arr.max()), arr.shape, arr.dtype)
+        arr = arr.copy()
+        arr[1] = 0.0
+        return arr, [False, True]
+
+    pipe.safety_checker = checker
+    try:
+        u8 = pipe.decode_latents(z, "uint8").cpu().numpy()
+        pil = pipe.decode_latents(z, "pil")
+    finally:
+        pipe.safety_checker = None
+    lo, hi, shape, dt = seen["range"]
+    assert 0.0 <= lo and hi <= 1.0 and shape == (2, 32, 32, 3) and dt == np.float32
+    assert np.array_equal(u8[0], plain[0]) and not u8[1].any() and not np.asarray(pil[1]).any()
+
+
+@pytest.mark.parametrize("mode", ["highres", "lowres"])
+def test_from_pretrained_reads_the_lavit_checkpoint_layout(tmp_path, mode):
+    # lavit_for_pigeon.py:148,166-170,185-191 + modeling_decoder.py:340-351 + modeling_visual_tokenzier.py:437-442
+    import json
+    from pigeon_amd.pipeline import PigeonPixelDecoder
+    from pigeon_amd.token_decoder import HighresVQDecoder, VQDecoder
+    from pigeon_amd.unet import UNet2DConditionModel
+    from pigeon_amd.vae import AutoencoderKL
+    low = mode == "lowres"
+    unet = UNet2DConditionModel(**(TINY_SD15 if low else TINY_UNET))
+    vae = AutoencoderKL(**TINY_VAE)
+    dec = (VQDecoder if low else HighresVQDecoder)(depth=1)
+    root = tmp_path / "LaVIT"
+    diff = root / ("pixel_decoding" if low else "highres_pixel_decoding")
+    for sub in ("unet", "vae", "scheduler"):
+        (diff / sub).mkdir(parents=True)
+    (root / "visual_tokenizer").mkdir()
+    sds = {"unet": weights.synth_like(unet, 1), "vae": weights.synth_like(vae, 2), "dec": weights.synth_like(dec, 3)}
+    torch.save(sds["unet"], diff / "unet" / "diffusion_pytorch_model.bin")
+    torch.save(sds["vae"], diff / "vae" / "diffusion_pytorch_model.bin")
+    json.dump({k: v for k, v in unet.config.items()}, open(diff / "unet" / "config.json", "w"))
+    json.dump({k: v for k, v in vae.config.items()}, open(diff / "vae" / "config.json", "w"))
+    json.dump(dict(SCHED, _class_name="DDIMScheduler"), open(diff / "scheduler" / "scheduler_config.json", "w"))
+    torch.save(sds["dec"], root / "visual_tokenizer" / ("tokenizer_decoder.bin" if low else "highres_tokenizer_decoder.bin"))
+    codebook = weights.synth_codebook()
+    torch.save({"quantize.embedding.weight": codebook, "encoder.something": torch.zeros(3)},
+               root / "visual_tokenizer" / "tokenizer_encoder.bin")
+    if low:
+        torch.save(torch.randn(1, 77, 768), diff / "uncond_embeddings.bin")
+    pipe = PigeonPixelDecoder.from_pretrained(str(root), pixel_decoding=mode, device=DEV, decoder_depth=1)
+    assert pipe.pixel_decoding == mode and torch.equal(pipe.codebook.cpu(), codebook)
+    assert torch.equal(pipe.unet.state_dict()["conv_in.weight"].cpu(), sds["unet"]["conv_in.weight"].to(torch.bfloat16))
+    assert pipe.scheduler.config.steps_offset == 1 and pipe.vae.dtype == torch.bfloat16
+    out = pipe.generate_image(image_tokens=weights.synth_tokens(1, seed=2), width=128, height=128, num_inference_steps=1,
+                              guidance_scale_for_diffusion=3.0, generator=None if not low else torch.Generator().manual_seed(0))
+    assert len(out) == (2 if low else 3) and out[0][0].size == (32, 32)
+
+
 def test_generate_image_per_step_latents_match_oracle(stack):
     pipe = stack["pipe"]
     tokens = weights.synth_tokens(2, seed=9)
