@@ -43,6 +43,24 @@ __device__ __forceinline__ float nh_param(const void* p, int dt, size_t i, float
     return dt == PGN_BF16 ? Cvt<PGN_BF16>::to_f32(h) : Cvt<PGN_F16>::to_f32(h);
 }
 
+// eight consecutive parameters starting at an element index that is a multiple of 8 (16-byte aligned rows: C % 8 == 0,
+// 16-byte aligned base): one or two 16-byte loads instead of eight scalar ones in every workgroup's prologue
+__device__ __forceinline__ void nh_param8(const void* p, int dt, size_t i, float dflt, float (&out)[8]) {
+    if (p == nullptr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = dflt;
+    } else if (dt == PGN_F32) {
+        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p) + i);
+        const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p) + i + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { out[j] = lo[j]; out[4 + j] = hi[j]; }
+    } else {
+        const u16x8_t v = *reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(p) + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = dt == PGN_BF16 ? Cvt<PGN_BF16>::to_f32(v[j]) : Cvt<PGN_F16>::to_f32(v[j]);
+    }
+}
+
 template <int DT>
 __device__ __forceinline__ void nh_load8(const NhArgs& a, size_t elem, const float (&t)[8], bool has_add, float (&f)[8]) {
     const u16x8_t v = *reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(a.x) + elem);
@@ -72,10 +90,7 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArg
 #pragma unroll
     for (int j = 0; j < 8; ++j) { tadd[j] = 0.f; piv[j] = 0.f; s[j] = 0.f; q[j] = 0.f; }
     if (active) {
-        if (has_add) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) tadd[j] = nh_param(a.addnc, a.add_dt, (size_t)n * a.C + cc * 8 + j, 0.f);
-        }
+        if (has_add) nh_param8(a.addnc, a.add_dt, (size_t)n * a.C + cc * 8, 0.f, tadd);
         nh_load8<DT>(a, img + (size_t)cc * 8, tadd, has_add, piv);   // row 0 of the sample: one pivot per channel
         const int row1 = min(a.HW, (sc + 1) * a.rows);
         const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x) + img + (size_t)cc * 8;
@@ -168,14 +183,14 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArg
     const size_t img = (size_t)n * a.HW * a.C;
     const bool has_add = a.addnc != nullptr;
     float tadd[8], mean[8], ga[8], be[8];
+    nh_param8(has_add ? a.addnc : nullptr, a.add_dt, (size_t)n * a.C + cc * 8, 0.f, tadd);
+    nh_param8(a.gamma, a.adt, (size_t)cc * 8, 1.f, ga);
+    nh_param8(a.beta, a.adt, (size_t)cc * 8, 0.f, be);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int c = cc * 8 + j;
-        tadd[j] = has_add ? nh_param(a.addnc, a.add_dt, (size_t)n * a.C + c, 0.f) : 0.f;
-        const float2 st = a.stats[(size_t)n * a.G + c / a.cpg];
+        const float2 st = a.stats[(size_t)n * a.G + (cc * 8 + j) / a.cpg];
         mean[j] = st.x;
-        ga[j] = nh_param(a.gamma, a.adt, c, 1.f) * st.y;
-        be[j] = nh_param(a.beta, a.adt, c, 0.f);
+        ga[j] *= st.y;
     }
     const int row1 = min(a.HW, (sc + 1) * a.rows);
     unsigned short* yp = reinterpret_cast<unsigned short*>(a.y);
@@ -206,6 +221,9 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArg
     }
 }
 
+// tuning hook (not part of the ABI): workgroups aimed at per launch, minimum rows per lane
+int g_nh_target_wgs = 768, g_nh_min_rows_per_lane = 24;   // swept on MI355X (scripts/gn_exp.py): fewer, longer workgroups
+
 // geometry shared by the workspace query and the launch
 static bool nh_geometry(int N, int C, int HW, int G, NhArgs* a) {
     if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return false;
@@ -215,11 +233,11 @@ static bool nh_geometry(int N, int C, int HW, int G, NhArgs* a) {
     if (R > HW) R = HW;
     if (R > 64) R = 64;
     a->R = R;
-    long long target = 2048 / N;                 // ~8 workgroups per CU over the whole launch
+    long long target = g_nh_target_wgs / N;      // ~8 workgroups per CU over the whole launch
     if (target < 1) target = 1;
     if (target > 64) target = 64;
     long long rows = (HW + target - 1) / target;
-    if (rows < 8LL * R) rows = 8LL * R;         // at least 8 rows per lane: amortise the LDS reduction
+    if (rows < (long long)g_nh_min_rows_per_lane * R) rows = (long long)g_nh_min_rows_per_lane * R;   // amortise the LDS reduction
     if (rows > HW) rows = HW;
     a->rows = (int)rows;
     a->S = (int)((HW + rows - 1) / rows);
@@ -227,6 +245,11 @@ static bool nh_geometry(int N, int C, int HW, int G, NhArgs* a) {
 }
 
 }  // namespace
+
+extern "C" void pgn_groupnorm_nhwc_tuning(int target_wgs, int min_rows_per_lane) {
+    g_nh_target_wgs = target_wgs;
+    g_nh_min_rows_per_lane = min_rows_per_lane;
+}
 
 extern "C" size_t pgn_groupnorm_nhwc_workspace_bytes(int N, int C, int HW, int G) {
     NhArgs a;
@@ -248,6 +271,10 @@ extern "C" int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const 
     if (!nh_geometry(N, C, HW, G, &a)) return PGN_ERR_UNSUPPORTED;
     if ((long long)N * a.S > 0x7fffffffLL || (long long)N * HW * C > 0x7fffffffffffLL) return PGN_ERR_UNSUPPORTED;
     if (!pgn_aligned(x, 16) || !pgn_aligned(y, 16) || !pgn_aligned(workspace, 8)) return PGN_ERR_INVALID;
+    // gamma / beta / add_nc rows are read as 16-byte vectors
+    if ((gamma != nullptr && (!pgn_aligned(gamma, 16) || !pgn_aligned(beta, 16))) ||
+        (add_nc != nullptr && !pgn_aligned(add_nc, 16)))
+        return PGN_ERR_INVALID;
     const size_t need = ((size_t)N * a.S * C + (size_t)N * G) * sizeof(float2);
     if (workspace_bytes < need) return PGN_ERR_INVALID;
     a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.addnc = add_nc; a.adt = affine_dtype; a.add_dt = add_dtype;
