@@ -178,6 +178,19 @@ int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, in
                       int64_t o_sh, const float* key_bias, int64_t bias_sb, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Row softmax of materialised attention scores:  probs[m, :] = softmax(scale * scores[m, :]).
+ * Middle step of the VAE decoder's single 512-wide attention head (diffusers AutoencoderKL mid-block Attention, reached
+ * through `self.vae.decode(...)` at lavit_for_pigeon.py:774; the reference leaves it on diffusers' default processor:
+ * only self.unet is switched to xformers at :202): scores = q k^T from a 16-bit GEMM with fp32 output, probs go into the
+ * second GEMM in the activation type.  fp32 statistics; same rounding points as the fused kernel (fp32 softmax, 16-bit
+ * P).  scores: fp32 [M, N] rows of ld_scores elements (16-byte aligned, ld % 4 == 0); probs: bf16 / f16 [M, N] rows of
+ * ld_probs elements (ld % 4 == 0); scale > 0.
+ * Algorithmic bytes: M*N*(4 + sizeof(elem)).
+ */
+int pgn_softmax_rows(const float* scores, int64_t ld_scores, void* probs, int probs_dtype, int64_t ld_probs, int64_t M,
+                     int64_t N, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * GEGLU gate of the transformer feed-forward: y[m, j] = h[m, j] * gelu(h[m, D + j]), exact (erf) GELU.
  * Replaces diffusers 0.27.2 GEGLU.forward (`hidden, gate = proj(x).chunk(2, dim=-1); hidden * F.gelu(gate)`)
  * inside BasicTransformerBlock.ff, reached through `self.unet(...)` at lavit_for_pigeon.py:752-757 — in torch

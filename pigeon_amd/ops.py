@@ -383,6 +383,47 @@ def clip_scores(image_features: torch.Tensor, text_features: Optional[torch.Tens
     return tgt, hs
 
 
+def softmax_rows(scores: torch.Tensor, scale: float, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """softmax(scale * scores) over the last dim of an fp32 [M, N] matrix, written in `out_dtype` (bf16 / fp16)."""
+    lib = _lib.load()
+    _dev(scores)
+    if scores.dim() != 2 or scores.dtype != torch.float32:
+        raise TypeError("softmax_rows expects an fp32 [M, N] matrix")
+    M, N = scores.shape
+    if scores.stride(1) != 1 or scores.stride(0) % 4 != 0 or scores.data_ptr() % 16 != 0:
+        # rows must start on 16 bytes: re-pitch into a buffer whose leading dimension is a multiple of 4
+        pitched = torch.empty(M, (N + 3) // 4 * 4, dtype=torch.float32, device=scores.device)[:, :N]
+        pitched.copy_(scores)
+        scores = pitched
+    out = torch.empty(M, (N + 3) // 4 * 4, dtype=out_dtype, device=scores.device)[:, :N]
+
+    def run():
+        rc = lib.pgn_softmax_rows(_ptr(scores), scores.stride(0), _ptr(out), _DT[out_dtype], out.stride(0), M, N,
+                                  float(scale), _stream())
+        _lib.check(rc, "pgn_softmax_rows")
+
+    _launch("softmax_rows", float(M * N * (4 + out.element_size())), run)
+    return out
+
+
+def wide_head_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
+                        rows_per_chunk: int = 8192) -> torch.Tensor:
+    """softmax(q k^T * scale) v for ONE head whose dim exceeds the fused kernel's 256 (the VAE's 512): per chunk of
+    query rows a 16-bit GEMM with fp32 output (hipBLASLt), pgn_softmax_rows, a second GEMM.  q: [Nq, D], k/v: [Nk, D],
+    bf16 / fp16.  The score chunk (rows_per_chunk x Nk fp32) is the only intermediate: 512 MiB at Nk = 16384."""
+    _dev(q, k, v)
+    if q.dim() != 2 or k.dim() != 2 or v.dim() != 2 or q.dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError("wide_head_attention expects 16-bit [N, D] matrices")
+    out = torch.empty(q.shape[0], v.shape[1], dtype=q.dtype, device=q.device)
+    kt = k.t()
+    for r0 in range(0, q.shape[0], rows_per_chunk):
+        s = torch.mm(q[r0:r0 + rows_per_chunk], kt, out_dtype=torch.float32)
+        p = softmax_rows(s, scale, q.dtype)
+        del s
+        torch.mm(p, v, out=out[r0:r0 + rows_per_chunk])
+    return out
+
+
 def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: Optional[torch.Tensor],
                    bias: Optional[torch.Tensor], eps: float = 1e-5):
     """LayerNorm over the last dim of (x + residual).  Returns (sum, normed); sum is x itself when residual is None."""

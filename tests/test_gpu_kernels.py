@@ -527,3 +527,31 @@ def test_bias_residual_add_rejects_unvectorisable_shapes(ops):
         ops.bias_residual_add(x, torch.zeros(4, device=DEV, dtype=torch.bfloat16))
     with pytest.raises(ValueError):
         ops.bias_residual_add(x[:, :, :, :2], torch.zeros(4, device=DEV, dtype=torch.bfloat16))
+
+
+@pytest.mark.parametrize("shape", [(5, 16384), (3, 1000), (2, 7), (4, 4100), (1, 1)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_softmax_rows_matches_fp32_softmax(ops, shape, dtype):
+    g = torch.Generator().manual_seed(sum(shape))
+    s = torch.randn(*shape, generator=g) * 20.0
+    if shape[1] > 100:
+        s[0, 17] = 300.0                     # a spike: everything else underflows, no NaN
+    got = ops.softmax_rows(s.to(DEV), 0.25, dtype)
+    want = torch.softmax(s * 0.25, dim=-1)
+    assert got.dtype == dtype and not torch.isnan(got.float()).any()
+    ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    assert (got.float().cpu() - want).abs().max().item() <= ulp * want.max().item() + 1e-7   # one rounding of P
+    assert torch.allclose(got.float().sum(-1).cpu(), torch.ones(shape[0]), atol=4 * ulp)
+
+
+def test_wide_head_attention_matches_oracle(ops):
+    # the VAE's head shape (one 512-wide head), ragged lengths, two query chunks
+    for Nq, Nk, D in ((300, 260, 512), (1024, 1024, 512), (64, 128, 320)):
+        g = torch.Generator().manual_seed(Nq + D)
+        q = torch.randn(1, Nq, D, generator=g).bfloat16()
+        k = torch.randn(1, Nk, D, generator=g).bfloat16()
+        v = torch.randn(1, Nk, D, generator=g).bfloat16()
+        want = ops_ref.attention_ref(q, k, v, 1, D ** -0.5, None).float()[0]
+        got = ops.wide_head_attention(q[0].to(DEV), k[0].to(DEV), v[0].to(DEV), D ** -0.5, rows_per_chunk=256).float().cpu()
+        err = (got - want).abs().max().item()
+        assert err < 2.0 ** -7 * max(1.0, want.abs().max().item()), (Nq, Nk, D, err)
