@@ -246,7 +246,7 @@ def main():
         n, work, secs = agg["attention"]
         ach = work / secs / 1e12
         # the UNet's instantiation (bf16, no key bias, 4 waves, head dim 64); other head dims are timed as their own kind
-        traffic, src = pmc_traffic("pgn_attn_fwd_kernel<1, false, 4, 2, 64, false>")
+        traffic, src = pmc_traffic("pgn_attn_fwd_kernel<1, false, 4, 3, 64, false>")
         roofline = {"kernel": "pgn_attn_fwd_kernel<bf16, head_dim 64>", "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": src, "launches": n, "avg_launch_us": secs / n * 1e6,

@@ -414,8 +414,8 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     do {                                                                                                          \
         if (D == 64) {                                                                                            \
             if (nw == 8) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 8, 2, 64, false>), grid, block, 0, s, a); \
-            else hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 64, false>), grid, block, 0, s, a);        \
-        } else if (D < 64) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 64, true>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 3, 64, false>), grid, block, 0, s, a);        \
+        } else if (D < 64) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 3, 64, true>), grid, block, 0, s, a); \
         else if (D == 128) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 128, false>), grid, block, 0, s, a); \
         else if (D < 128) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 128, true>), grid, block, 0, s, a); \
         else if (D == 256) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 1, 256, false>), grid, block, 0, s, a); \
