@@ -56,6 +56,12 @@ def main():
         x = ops.cfg_expand_scale(torch.randn(B, 4, h, w, device=dev), torch.bfloat16, 1.0)
         pipe.unet(x, 961, encoder_hidden_states=ctx, added_cond_kwargs={"text_embeds": add, "time_ids": ids})
         torch.cuda.synchronize()
+        # the pipeline runs cross-attention on the conditional half only (HipAttnProcessor.zero_ctx_rows): those
+        # projections have half the rows
+        pipe.unet.set_zero_context_rows(B)
+        pipe.unet(x, 961, encoder_hidden_states=ctx, added_cond_kwargs={"text_embeds": add, "time_ids": ids})
+        pipe.unet.set_zero_context_rows(0)
+        torch.cuda.synchronize()
         print(f"[{time.perf_counter() - t0:6.0f}s] unet tuned", flush=True)
         pipe.decode_latents(torch.randn(1, 4, h, w, device=dev), "uint8")
         torch.cuda.synchronize()
