@@ -246,6 +246,14 @@ int pgn_bias_residual_add(const void* x, const void* residual, const void* bias,
 int pgn_add_layernorm(const void* x, const void* residual, void* sum_out, void* y, const void* gamma,
                       const void* beta, int dtype, int affine_dtype, int64_t M, int C, float eps, void* stream);
 
+/* Same, with a pending per-channel bias: s = x + col_bias[c] (+ residual).  Lets the attention output projections run
+ * as bias-free GEMMs that accumulate straight into the residual buffer (beta = 1): the bias they owe travels as an
+ * fp32 [C] vector into the next LayerNorm instead of costing a pass over the activations, and that LayerNorm reads one
+ * tensor and writes one (2 passes) where add + norm took 4.  col_bias: fp32 [C], 16-byte aligned, or NULL. */
+int pgn_add_layernorm_cb(const void* x, const void* residual, void* sum_out, void* y, const void* gamma,
+                         const void* beta, int dtype, int affine_dtype, const float* col_bias, int64_t M, int C,
+                         float eps, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * VAE output -> displayable bytes in one pass: y[n, h, w, c] = uint8(rint(clamp(float(x[n, c, h, w]) / 2 + 0.5, 0, 1)
  * * 255)), rint = round half to even.  Replaces lavit_for_pigeon.py:780-782 (`image.float()`, `/ 2 + 0.5`,

@@ -157,13 +157,23 @@ def geglu_ref(h: torch.Tensor) -> torch.Tensor:
     return hidden * F.gelu(gate)
 
 
-def add_layer_norm_ref(x: torch.Tensor, residual: Optional[torch.Tensor], weight, bias, eps: float = 1e-5):
+def add_layer_norm_ref(x: torch.Tensor, residual: Optional[torch.Tensor], weight, bias, eps: float = 1e-5,
+                       col_bias: Optional[torch.Tensor] = None):
     """`s = x + residual` in the io dtype (diffusers BasicTransformerBlock residual adds), then F.layer_norm in fp32
-    (autocast runs layer_norm in fp32) rounded once to the io dtype.  Returns (s, y, y_fp32).  PARITY UNPINNED."""
-    s = x if residual is None else x + residual
+    (autocast runs layer_norm in fp32) rounded once to the io dtype.  Returns (s, y, y_fp32).  PARITY UNPINNED.
+    `col_bias` (fp32 [C]): the bias a bias-free accumulating projection still owes — s = x + col_bias (+ residual)
+    with one rounding when a residual materialises the sum; without one the norm sees the unrounded fp32 value."""
+    if col_bias is None:
+        s = x if residual is None else x + residual
+        sn = s.float()
+    elif residual is None:
+        s, sn = x, x.float() + col_bias.float()
+    else:
+        s = (x.float() + col_bias.float() + residual.float()).to(x.dtype)
+        sn = s.float()
     w = None if weight is None else weight.float()
     b = None if bias is None else bias.float()
-    y32 = F.layer_norm(s.float(), (s.shape[-1],), w, b, eps)
+    y32 = F.layer_norm(sn, (s.shape[-1],), w, b, eps)
     return s, y32.to(x.dtype), y32
 
 

@@ -94,6 +94,50 @@ class HipAttnProcessor:
         return hidden_states
 
 
+    # ---- residual-accumulating form (BasicTransformerBlock) ------------------------------------------------------
+    @staticmethod
+    def can_accumulate(attn: "Attention", hidden_states: torch.Tensor) -> bool:
+        lin = attn.to_out[0]
+        return (hidden_states.dim() == 3 and hidden_states.is_cuda
+                and hidden_states.dtype in (torch.bfloat16, torch.float16) and isinstance(lin, nn.Linear)
+                and lin.out_features == hidden_states.shape[-1] and getattr(attn, "spatial_norm", None) is None
+                and getattr(attn, "group_norm", None) is None and not getattr(attn, "norm_cross", None)
+                and not attn.residual_connection and attn.rescale_output_factor == 1.0)
+
+    def accumulate(self, attn: "Attention", hidden_states: torch.Tensor, residual: torch.Tensor,
+                   encoder_hidden_states: Optional[torch.Tensor] = None,
+                   attention_mask: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """residual += attention(hidden_states) @ to_out.weight^T IN PLACE (a GEMM with beta = 1: no separate add
+        launch) and return to_out's bias, which the caller carries as a pending per-channel vector into the next
+        LayerNorm (ops.add_layer_norm col_bias).  Rows of an all-zero context (zero_ctx_rows) receive nothing."""
+        B, N, C = hidden_states.shape
+        is_cross = encoder_hidden_states is not None
+        k0 = self.zero_ctx_rows
+        if not (is_cross and 0 < k0 < B and attention_mask is None and attn.to_k.bias is None
+                and attn.to_v.bias is None):
+            k0 = 0
+        hs = hidden_states[k0:]
+        query = attn.to_q(hs)
+        context = hs if not is_cross else encoder_hidden_states[k0:]
+        if is_cross and self.cache_cross_kv and self._kv_cache is not None and self._kv_cache[0] is encoder_hidden_states:
+            key, value = self._kv_cache[1], self._kv_cache[2]
+        else:
+            key, value = attn.to_k(context), attn.to_v(context)
+            if is_cross and self.cache_cross_kv:
+                self._kv_cache = (encoder_hidden_states, key, value)
+        key_bias = None
+        if attention_mask is not None:
+            m = attention_mask
+            if m.dim() == 3 and m.shape[1] == 1:
+                m = m[:, 0, :]
+            if m.dim() != 2 or m.shape[0] not in (B, 1) or m.shape[1] != key.shape[1]:
+                raise NotImplementedError("HipAttnProcessor supports key-padding masks [B, Nk] / [B, 1, Nk] only")
+            key_bias = m.to(torch.float32).expand(B, -1)[k0:]
+        o = ops.attention(query, key, value, attn.heads, attn.scale, key_bias)
+        lin = attn.to_out[0]
+        residual[k0:].view(-1, C).addmm_(o.view(-1, o.shape[-1]), lin.weight.t())
+        return lin.bias
+
     def _cross_skip_zero_rows(self, attn, hidden_states, encoder_hidden_states, k0):
         B, N, _ = hidden_states.shape
         query = attn.to_q(hidden_states[k0:])

@@ -141,7 +141,7 @@ template <int DT, int R, bool HAS_RES>
 __global__ __launch_bounds__(EW_THREADS) void pgn_add_layernorm_kernel(
     const unsigned short* __restrict__ x, const unsigned short* __restrict__ res, unsigned short* __restrict__ sum_out,
     unsigned short* __restrict__ y, const void* __restrict__ gamma, const void* __restrict__ beta, int adt, long long M,
-    int C, float eps) {
+    int C, float eps, const float* __restrict__ cb) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (EW_THREADS / 64) + (threadIdx.x >> 6);
     if (row >= M) return;   // whole wavefront leaves together: no barrier in this kernel
@@ -154,6 +154,12 @@ __global__ __launch_bounds__(EW_THREADS) void pgn_add_layernorm_kernel(
         const int v = lane + 64 * r;
         if (v < C8) {
             unpack8<DT>(*reinterpret_cast<const u16x8_t*>(xr + 8 * v), f[r]);
+            if (cb != nullptr) {   // pending per-channel bias of bias-free GEMMs accumulated into x (uniform branch)
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cb + 8 * v);
+                const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cb + 8 * v + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[r][j] += lo[j]; f[r][4 + j] += hi[j]; }
+            }
             if constexpr (HAS_RES) {
                 float g[8];
                 unpack8<DT>(*reinterpret_cast<const u16x8_t*>(res + row * C + 8 * v), g);
@@ -263,7 +269,14 @@ extern "C" int pgn_geglu(const void* h, void* y, int dtype, int64_t M, int D, in
 extern "C" int pgn_add_layernorm(const void* x, const void* residual, void* sum_out, void* y, const void* gamma,
                                  const void* beta, int dtype, int affine_dtype, int64_t M, int C, float eps,
                                  void* stream) {
+    return pgn_add_layernorm_cb(x, residual, sum_out, y, gamma, beta, dtype, affine_dtype, nullptr, M, C, eps, stream);
+}
+
+extern "C" int pgn_add_layernorm_cb(const void* x, const void* residual, void* sum_out, void* y, const void* gamma,
+                                    const void* beta, int dtype, int affine_dtype, const float* col_bias, int64_t M,
+                                    int C, float eps, void* stream) {
     if (x == nullptr || y == nullptr) return PGN_ERR_INVALID;
+    if (col_bias != nullptr && !pgn_aligned(col_bias, 16)) return PGN_ERR_INVALID;
     if ((residual == nullptr) != (sum_out == nullptr)) return PGN_ERR_INVALID;
     if ((gamma == nullptr) != (beta == nullptr)) return PGN_ERR_INVALID;
     if (M <= 0 || C <= 0 || !(eps >= 0.f)) return PGN_ERR_INVALID;
@@ -280,7 +293,7 @@ extern "C" int pgn_add_layernorm(const void* x, const void* residual, void* sum_
 #define PGN_LN_LAUNCH(DT, R, RES)                                                                             \
     hipLaunchKernelGGL((pgn_add_layernorm_kernel<DT, R, RES>), grid, block, 0, s, (const unsigned short*)x,    \
                        (const unsigned short*)residual, (unsigned short*)sum_out, (unsigned short*)y, gamma,  \
-                       beta, affine_dtype, (long long)M, C, eps)
+                       beta, affine_dtype, (long long)M, C, eps, col_bias)
 #define PGN_LN_R(DT, RES)                       \
     do {                                        \
         if (r <= 1) PGN_LN_LAUNCH(DT, 1, RES);  \

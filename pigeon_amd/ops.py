@@ -425,8 +425,9 @@ def wide_head_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale
 
 
 def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: Optional[torch.Tensor],
-                   bias: Optional[torch.Tensor], eps: float = 1e-5):
-    """LayerNorm over the last dim of (x + residual).  Returns (sum, normed); sum is x itself when residual is None."""
+                   bias: Optional[torch.Tensor], eps: float = 1e-5, col_bias: Optional[torch.Tensor] = None):
+    """LayerNorm over the last dim of (x + col_bias + residual).  Returns (sum, normed); sum is x itself when residual
+    is None (a pending `col_bias` [C] then stays pending: it is applied to the norm's input only)."""
     lib = _lib.load()
     _dev(x, residual, weight, bias)
     C = x.shape[-1]
@@ -446,11 +447,15 @@ def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], weight: Op
         adt = _dt(weight)
     y = torch.empty_like(x)
     s = torch.empty_like(x) if residual is not None else None
+    if col_bias is not None:
+        if col_bias.numel() != C:
+            raise ValueError("col_bias must be [C]")
+        col_bias = col_bias.to(torch.float32).contiguous()
 
     def run():
-        rc = lib.pgn_add_layernorm(_ptr(x), _ptr(residual), _ptr(s), _ptr(y), _ptr(weight), _ptr(bias), _dt(x), adt,
-                                   M, C, float(eps), _stream())
-        _lib.check(rc, "pgn_add_layernorm")
+        rc = lib.pgn_add_layernorm_cb(_ptr(x), _ptr(residual), _ptr(s), _ptr(y), _ptr(weight), _ptr(bias), _dt(x), adt,
+                                      _ptr(col_bias), M, C, float(eps), _stream())
+        _lib.check(rc, "pgn_add_layernorm_cb")
 
     _launch("layernorm", float(x.numel() * x.element_size() * (4 if residual is not None else 2)), run)
     return (s if residual is not None else x), y

@@ -58,6 +58,10 @@ SD15_CONFIG = dict(
 )
 
 
+# A/B switch for measurements: PGN_ACCUMULATE_ATTENTION=0 restores add + LayerNorm after every attention layer
+ACCUMULATE_ATTENTION = os.environ.get("PGN_ACCUMULATE_ATTENTION", "1") != "0"
+
+
 class GEGLU(nn.Module):
     def __init__(self, dim_in: int, dim_out: int):
         super().__init__()
@@ -89,21 +93,51 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim, eps=1e-5)
         self.ff = FeedForward(dim)
 
+    def _pending_biases(self):
+        """fp32 [C] vectors (b_attn1, b_attn1 + b_attn2) owed by the bias-free accumulating output projections; cached
+        per parameter storage (inference: the weights are frozen)."""
+        b1, b2 = self.attn1.to_out[0].bias, self.attn2.to_out[0].bias
+        key = (None if b1 is None else (b1.data_ptr(), b1.dtype), None if b2 is None else (b2.data_ptr(), b2.dtype))
+        if getattr(self, "_cb_key", None) != key:
+            c1 = None if b1 is None else b1.detach().float()
+            c12 = c1 if b2 is None else (b2.detach().float() if c1 is None else c1 + b2.detach().float())
+            self._cb_key, self._cb = key, (c1, c12)
+        return self._cb
+
     def forward(self, hidden_states, encoder_hidden_states=None, encoder_attention_mask=None, attention_mask=None,
-                pending=None, defer_add=False):
+                pending=None, defer_add=False, col_bias=None, owns_input=False):
         """diffusers BasicTransformerBlock.forward: x += attn1(norm1(x)); x += attn2(norm2(x), ctx); x += ff(norm3(x)).
-        Each residual add is fused with the LayerNorm that consumes the sum (ops.add_layer_norm, one pass).
-        `pending` is a tensor still to be added to `hidden_states` (the previous block's feed-forward output);
-        with `defer_add` the block returns (x, ff_out) and leaves the last add to its consumer."""
+        `pending` is a tensor still to be added to `hidden_states` (the previous block's feed-forward output) and
+        `col_bias` a per-channel vector still owed to it; with `defer_add` the block returns (x, ff_out, col_bias) and
+        leaves the last add to its consumer.
+        On the HIP processor the two attention output projections ACCUMULATE into the residual buffer (GEMM with
+        beta = 1, in place) and their biases ride as a pending fp32 [C] vector into the next LayerNorm: norm2 / norm3
+        read one tensor and write one (2 passes) instead of add + norm (4 passes).  Other processors keep the
+        add-fused-with-LayerNorm form."""
         n1, n2, n3 = self.norm1, self.norm2, self.norm3
-        hidden_states, h = ops.add_layer_norm(hidden_states, pending, n1.weight, n1.bias, n1.eps)
+        hidden_states, h = ops.add_layer_norm(hidden_states, pending, n1.weight, n1.bias, n1.eps, col_bias=col_bias)
+        p1, p2 = self.attn1.processor, self.attn2.processor
+        if (ACCUMULATE_ATTENTION and isinstance(p1, HipAttnProcessor) and isinstance(p2, HipAttnProcessor)
+                and p1.can_accumulate(self.attn1, h) and p2.can_accumulate(self.attn2, h)):
+            if pending is None and not owns_input:
+                hidden_states = hidden_states.clone()     # do not accumulate into a tensor the caller may still use
+            c1, c12 = self._pending_biases()
+            p1.accumulate(self.attn1, h, hidden_states, None, attention_mask)
+            _, h = ops.add_layer_norm(hidden_states, None, n2.weight, n2.bias, n2.eps, col_bias=c1)
+            p2.accumulate(self.attn2, h, hidden_states, encoder_hidden_states, encoder_attention_mask)
+            _, h = ops.add_layer_norm(hidden_states, None, n3.weight, n3.bias, n3.eps, col_bias=c12)
+            f = self.ff(h)
+            if defer_add:
+                return hidden_states, f, c12
+            out = f + hidden_states
+            return out if c12 is None else out + c12.to(out.dtype)
         a = self.attn1(h, attention_mask=attention_mask)
         hidden_states, h = ops.add_layer_norm(a, hidden_states, n2.weight, n2.bias, n2.eps)
         a = self.attn2(h, encoder_hidden_states=encoder_hidden_states, attention_mask=encoder_attention_mask)
         hidden_states, h = ops.add_layer_norm(a, hidden_states, n3.weight, n3.bias, n3.eps)
         f = self.ff(h)
         if defer_add:
-            return hidden_states, f
+            return hidden_states, f, None
         return f + hidden_states
 
 
@@ -133,16 +167,25 @@ class Transformer2DModel(nn.Module):
         else:
             hidden_states = self.proj_in(hidden_states)
             hidden_states = hidden_states.permute(0, 2, 3, 1).reshape(b, h * w, -1)
-        pending = None
+        pending, cb = None, None
         for block in self.transformer_blocks:
-            hidden_states, pending = block(hidden_states, encoder_hidden_states, encoder_attention_mask,
-                                           attention_mask, pending=pending, defer_add=True)
+            hidden_states, pending, cb = block(hidden_states, encoder_hidden_states, encoder_attention_mask,
+                                               attention_mask, pending=pending, defer_add=True, col_bias=cb,
+                                               owns_input=True)   # proj_in's output is ours
         hidden_states = pending + hidden_states
+        if cb is not None and not self.use_linear_projection:
+            hidden_states = hidden_states + cb.to(hidden_states.dtype)
         # channels_last activations: [B, HW, C] IS the memory of the [B, C, H, W] tensor, so both reshapes are views;
         # NCHW activations need the transposing copy diffusers makes
         cl = residual.is_contiguous(memory_format=torch.channels_last) and not residual.is_contiguous()
         if self.use_linear_projection:
-            hidden_states = self.proj_out(hidden_states)
+            if cb is None:
+                hidden_states = self.proj_out(hidden_states)
+            else:
+                # the last block's pending bias goes through the projection as a bias term: W (x + cb) + b
+                po = self.proj_out
+                b_eff = (po.weight.float() @ cb + (0.0 if po.bias is None else po.bias.float())).to(hidden_states.dtype)
+                hidden_states = torch.nn.functional.linear(hidden_states, po.weight, b_eff)
             hidden_states = hidden_states.reshape(b, h, w, c).permute(0, 3, 1, 2)
             if not cl:
                 hidden_states = hidden_states.contiguous()

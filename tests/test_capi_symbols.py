@@ -74,6 +74,7 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.pgn_softmax_rows(p16, 8, p16, 1, 8, 1, 8, 0.0, None) == -1          # scale must be positive
     assert lib.pgn_softmax_rows(p16, 6, p16, 1, 8, 1, 6, 1.0, None) == -1          # leading dimension % 4
     assert lib.pgn_softmax_rows(p16, 8, p16, 0, 8, 1, 8, 1.0, None) == -2          # fp32 probabilities
+    assert lib.pgn_add_layernorm_cb(p16, None, None, p16, None, None, 1, 0, p16 + 4, 1, 8, 1e-5, None) == -1   # col_bias alignment
     assert lib.pgn_geglu(None, None, 1, 4, 8, 16, 8, None) == -1
     assert lib.pgn_geglu(p16, p16, 1, 4, 12, 24, 12, None) == -2
     assert lib.pgn_geglu(p16, p16, 0, 4, 8, 16, 8, None) == -2

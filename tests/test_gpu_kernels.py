@@ -555,3 +555,30 @@ def test_wide_head_attention_matches_oracle(ops):
         got = ops.wide_head_attention(q[0].to(DEV), k[0].to(DEV), v[0].to(DEV), D ** -0.5, rows_per_chunk=256).float().cpu()
         err = (got - want).abs().max().item()
         assert err < 2.0 ** -7 * max(1.0, want.abs().max().item()), (Nq, Nk, D, err)
+
+
+@pytest.mark.parametrize("with_res", [False, True])
+@pytest.mark.parametrize("shape", [(2, 100, 1280), (3, 7, 640), (1, 5, 8)])
+def test_add_layernorm_with_pending_column_bias(ops, shape, with_res):
+    # pgn_add_layernorm_cb: the bias owed by a bias-free accumulating projection enters as an fp32 [C] vector
+    g = torch.Generator().manual_seed(shape[1])
+    C = shape[-1]
+    x = (torch.randn(shape, generator=g) * 1.5).bfloat16()
+    r = (torch.randn(shape, generator=g) * 0.7).bfloat16() if with_res else None
+    cb = torch.randn(C, generator=g) * 0.5
+    w = (1 + 0.2 * torch.randn(C, generator=g)).bfloat16()
+    b = (0.2 * torch.randn(C, generator=g)).bfloat16()
+    want_s, _, want32 = ops_ref.add_layer_norm_ref(x, r, w, b, 1e-5, col_bias=cb)
+    got_s, got_y = ops.add_layer_norm(x.to(DEV), None if r is None else r.to(DEV), w.to(DEV), b.to(DEV), 1e-5,
+                                      col_bias=cb.to(DEV))
+    if with_res:
+        assert (got_s.cpu() != want_s).float().mean().item() < 0.01      # x + cb + r: fp32 add order may differ
+        assert (got_s.cpu().float() - want_s.float()).abs().max() <= 2.0 ** -7 * want_s.float().abs().max()
+    else:
+        assert got_s.data_ptr() == got_s.data_ptr() and torch.equal(got_s.cpu(), x)   # the bias stays pending
+    ulp = 2.0 ** -7
+    err = (got_y.cpu().float() - want32).abs()
+    assert bool((err <= 2 * ulp * want32.abs() + 8 * ulp * 2.0 ** -7).all()), err.max().item()
+    # and it matters
+    _, plain = ops.add_layer_norm(x.to(DEV), None if r is None else r.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
+    assert (plain.cpu().float() - want32).abs().max() > 0.05
