@@ -60,6 +60,7 @@ SD15_CONFIG = dict(
 
 # A/B switch for measurements: PGN_ACCUMULATE_ATTENTION=0 restores add + LayerNorm after every attention layer
 ACCUMULATE_ATTENTION = os.environ.get("PGN_ACCUMULATE_ATTENTION", "1") != "0"
+ACCUMULATE_FF = os.environ.get("PGN_ACCUMULATE_FF", "1") != "0"
 
 
 class GEGLU(nn.Module):
@@ -93,39 +94,56 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim, eps=1e-5)
         self.ff = FeedForward(dim)
 
-    def _pending_biases(self):
-        """fp32 [C] vectors (b_attn1, b_attn1 + b_attn2) owed by the bias-free accumulating output projections; cached
-        per parameter storage (inference: the weights are frozen)."""
-        b1, b2 = self.attn1.to_out[0].bias, self.attn2.to_out[0].bias
-        key = (None if b1 is None else (b1.data_ptr(), b1.dtype), None if b2 is None else (b2.data_ptr(), b2.dtype))
+    def _pending_biases(self, cb_in):
+        """Running fp32 [C] totals of the biases owed by the bias-free accumulating GEMMs: what is pending after attn1,
+        after attn2 and after the feed-forward, on top of what the previous block left (`cb_in`).  Cached per parameter
+        storage and incoming vector (inference: frozen weights, the same chain of blocks every call)."""
+        bs = (self.attn1.to_out[0].bias, self.attn2.to_out[0].bias, self.ff.net[2].bias)
+        key = tuple(None if t is None else (t.data_ptr(), t.dtype) for t in bs + (cb_in,))
         if getattr(self, "_cb_key", None) != key:
-            c1 = None if b1 is None else b1.detach().float()
-            c12 = c1 if b2 is None else (b2.detach().float() if c1 is None else c1 + b2.detach().float())
-            self._cb_key, self._cb = key, (c1, c12)
+            tot, out = cb_in, []
+            for t in bs:
+                if t is not None:
+                    tot = t.detach().float() if tot is None else tot + t.detach().float()
+                out.append(tot)
+            self._cb_key, self._cb = key, tuple(out)
         return self._cb
 
     def forward(self, hidden_states, encoder_hidden_states=None, encoder_attention_mask=None, attention_mask=None,
                 pending=None, defer_add=False, col_bias=None, owns_input=False):
         """diffusers BasicTransformerBlock.forward: x += attn1(norm1(x)); x += attn2(norm2(x), ctx); x += ff(norm3(x)).
         `pending` is a tensor still to be added to `hidden_states` (the previous block's feed-forward output) and
-        `col_bias` a per-channel vector still owed to it; with `defer_add` the block returns (x, ff_out, col_bias) and
-        leaves the last add to its consumer.
-        On the HIP processor the two attention output projections ACCUMULATE into the residual buffer (GEMM with
-        beta = 1, in place) and their biases ride as a pending fp32 [C] vector into the next LayerNorm: norm2 / norm3
-        read one tensor and write one (2 passes) instead of add + norm (4 passes).  Other processors keep the
-        add-fused-with-LayerNorm form."""
+        `col_bias` a per-channel fp32 vector still owed to it; with `defer_add` the block returns
+        (x, pending, col_bias) and leaves the last adds to its consumer.
+        On the HIP processor the attention output projections and the feed-forward's second GEMM ACCUMULATE into the
+        residual buffer (GEMM with beta = 1, in place) and their biases ride as a pending fp32 [C] vector into the next
+        LayerNorm: every norm reads one tensor and writes one (2 passes) instead of add + norm (4 passes).  Other
+        processors keep the add-fused-with-LayerNorm form."""
         n1, n2, n3 = self.norm1, self.norm2, self.norm3
-        hidden_states, h = ops.add_layer_norm(hidden_states, pending, n1.weight, n1.bias, n1.eps, col_bias=col_bias)
         p1, p2 = self.attn1.processor, self.attn2.processor
-        if (ACCUMULATE_ATTENTION and isinstance(p1, HipAttnProcessor) and isinstance(p2, HipAttnProcessor)
-                and p1.can_accumulate(self.attn1, h) and p2.can_accumulate(self.attn2, h)):
-            if pending is None and not owns_input:
-                hidden_states = hidden_states.clone()     # do not accumulate into a tensor the caller may still use
-            c1, c12 = self._pending_biases()
+        accumulate = (ACCUMULATE_ATTENTION and isinstance(p1, HipAttnProcessor) and isinstance(p2, HipAttnProcessor)
+                      and p1.can_accumulate(self.attn1, hidden_states) and p2.can_accumulate(self.attn2, hidden_states))
+        if not accumulate and pending is None and col_bias is not None:
+            hidden_states = hidden_states + col_bias.to(hidden_states.dtype)      # nothing downstream carries it
+            col_bias = None
+        hidden_states, h = ops.add_layer_norm(hidden_states, pending, n1.weight, n1.bias, n1.eps, col_bias=col_bias)
+        if accumulate:
+            if pending is None:
+                cb_in = col_bias                          # still pending: norm1 only looked at it
+                if not owns_input:
+                    hidden_states = hidden_states.clone() # do not accumulate into a tensor the caller may still use
+            else:
+                cb_in = None                              # materialised into the fresh sum by norm1
+            c1, c12, c123 = self._pending_biases(cb_in)
             p1.accumulate(self.attn1, h, hidden_states, None, attention_mask)
             _, h = ops.add_layer_norm(hidden_states, None, n2.weight, n2.bias, n2.eps, col_bias=c1)
             p2.accumulate(self.attn2, h, hidden_states, encoder_hidden_states, encoder_attention_mask)
             _, h = ops.add_layer_norm(hidden_states, None, n3.weight, n3.bias, n3.eps, col_bias=c12)
+            lin2 = self.ff.net[2]
+            if ACCUMULATE_FF and defer_add and isinstance(lin2, nn.Linear):
+                g = self.ff.net[0](h)
+                hidden_states.view(-1, hidden_states.shape[-1]).addmm_(g.view(-1, g.shape[-1]), lin2.weight.t())
+                return hidden_states, None, c123
             f = self.ff(h)
             if defer_add:
                 return hidden_states, f, c12
@@ -172,7 +190,8 @@ class Transformer2DModel(nn.Module):
             hidden_states, pending, cb = block(hidden_states, encoder_hidden_states, encoder_attention_mask,
                                                attention_mask, pending=pending, defer_add=True, col_bias=cb,
                                                owns_input=True)   # proj_in's output is ours
-        hidden_states = pending + hidden_states
+        if pending is not None:
+            hidden_states = pending + hidden_states
         if cb is not None and not self.use_linear_projection:
             hidden_states = hidden_states + cb.to(hidden_states.dtype)
         # channels_last activations: [B, HW, C] IS the memory of the [B, C, H, W] tensor, so both reshapes are views;
