@@ -367,6 +367,39 @@ def test_zero_context_rows_shortcut_changes_nothing(stack):
     assert all(p.zero_ctx_rows == 0 for p in unet.attn_processors.values() if isinstance(p, HipAttnProcessor))
 
 
+def test_fused_qkv_projection_equals_separate_projections(stack, monkeypatch):
+    # self-attention runs to_q / to_k / to_v as one GEMM over the concatenated weights (HipAttnProcessor._self_qkv):
+    # each element is the same dot product, so the result equals three separate GEMMs up to tile selection; the
+    # fused weight follows the parameters (in-place writes and replaced storage both rebuild it)
+    from pigeon_amd import attention_processor as ap
+    attn = ap.Attention(128, heads=2, dim_head=64).to(DEV, torch.bfloat16)
+    g = torch.Generator().manual_seed(21)
+    hs = torch.randn(3, 80, 128, generator=g).to(DEV, torch.bfloat16)
+    fused = attn(hs)
+    assert attn._qkv_fused[1].shape == (384, 128)
+    monkeypatch.setattr(ap, "_FUSE_QKV", False)
+    separate = attn(hs)
+    monkeypatch.setattr(ap, "_FUSE_QKV", True)
+    assert _rel(fused, separate)[1] < 0.01
+    with torch.no_grad():
+        attn.to_k.weight.mul_(-0.5)
+    first = attn._qkv_fused[1]
+    changed = attn(hs)
+    assert attn._qkv_fused[1] is not first and _rel(changed, fused)[1] > 0.1
+    monkeypatch.setattr(ap, "_FUSE_QKV", False)
+    assert _rel(changed, attn(hs))[1] < 0.01
+    monkeypatch.setattr(ap, "_FUSE_QKV", True)
+    assert "_qkv_fused" not in attn.state_dict() and len(attn.state_dict()) == 5
+    # the whole UNet: fused and separate projections agree to the bf16 noise floor
+    x, ctx, pooled, ids = _unet_inputs(2, 16, 16, seed=9)
+    unet = stack["pipe"].unet
+    kw = dict(encoder_hidden_states=ctx.to(DEV), added_cond_kwargs={"text_embeds": pooled.to(DEV), "time_ids": ids.to(DEV)})
+    a = unet(x.to(DEV), 500, **kw).sample
+    monkeypatch.setattr(ap, "_FUSE_QKV", False)
+    b = unet(x.to(DEV), 500, **kw).sample
+    assert _rel(a, b)[1] < 0.02
+
+
 def test_hip_graph_replay_equals_eager_loop(stack):
     # enable_hip_graph(): the whole denoising loop is captured once per (shape, schedule, guidance) and replayed;
     # same kernels, same order -> same latents as the eager loop up to the GEMMs' run-to-run noise floor
