@@ -400,6 +400,24 @@ def test_fused_qkv_projection_equals_separate_projections(stack, monkeypatch):
     assert _rel(a, b)[1] < 0.02
 
 
+@pytest.mark.parametrize("switch", [("pigeon_amd.unet", "ACCUMULATE_ATTENTION"), ("pigeon_amd.unet", "ACCUMULATE_FF"),
+                                    ("pigeon_amd.layers", "FUSE_CONV_BIAS")])
+def test_host_side_restructurings_agree_with_the_plain_order(stack, monkeypatch, switch):
+    # every restructuring around the library GEMMs / convolutions (INTEGRATION.md switch table) is the same real
+    # arithmetic in another order: switched off, the UNet and the VAE agree with the default build to the bf16 floor
+    import importlib
+    mod = importlib.import_module(switch[0])
+    assert getattr(mod, switch[1]) is True
+    x, ctx, pooled, ids = _unet_inputs(2, 16, 20, seed=13)
+    pipe = stack["pipe"]
+    kw = dict(encoder_hidden_states=ctx.to(DEV), added_cond_kwargs={"text_embeds": pooled.to(DEV), "time_ids": ids.to(DEV)})
+    z = torch.randn(1, 4, 16, 20, generator=torch.Generator().manual_seed(3)).to(DEV, torch.bfloat16)
+    a, va = pipe.unet(x.to(DEV), 300, **kw).sample, pipe.vae.decode(z).sample
+    monkeypatch.setattr(mod, switch[1], False)
+    b, vb = pipe.unet(x.to(DEV), 300, **kw).sample, pipe.vae.decode(z).sample
+    assert _rel(a, b)[1] < 0.02 and _rel(va, vb)[1] < 0.02
+
+
 def test_hip_graph_replay_equals_eager_loop(stack):
     # enable_hip_graph(): the whole denoising loop is captured once per (shape, schedule, guidance) and replayed;
     # same kernels, same order -> same latents as the eager loop up to the GEMMs' run-to-run noise floor
