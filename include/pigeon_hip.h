@@ -155,6 +155,18 @@ int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const void* gamma
                             const void* add_nc, int add_dtype, int N, int C, int HW, int G, float eps, int act,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same GroupNorm (+SiLU) over the channel concatenation [x1 | x2] read in place: x1 is [N, HW, C1], x2 is
+ * [N, HW, C2], y is [N, HW, C1 + C2].  Replaces `hidden_states = torch.cat([hidden_states, res_hidden_states], dim=1)`
+ * of diffusers CrossAttnUpBlock2D.forward / UpBlock2D.forward (unet_2d_blocks.py, reached from
+ * lavit_for_pigeon.py:752-757) together with the `norm1` + SiLU of the ResnetBlock2D that consumes it: the
+ * concatenated tensor is never written.  Bit-identical to pgn_groupnorm_silu_nhwc on the materialised concatenation
+ * (same per-channel partial sums in the same order); groups may straddle the boundary.  C1 % 8 == 0, C2 % 8 == 0,
+ * other limits and the workspace (query with C = C1 + C2) as above.  Algorithmic bytes: 2 * N*HW*(C1+C2) * 2,
+ * against 4 * ... for cat + GroupNorm. */
+int pgn_groupnorm_silu_nhwc_cat(const void* x1, int C1, const void* x2, int C2, void* y, int dtype, const void* gamma,
+                                const void* beta, int affine_dtype, const void* add_nc, int add_dtype, int N, int HW,
+                                int G, float eps, int act, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-head attention forward, softmax(q k^T * scale + key_bias) v, flash-style on MFMA.
  * Replaces xformers.ops.memory_efficient_attention(q, k, v, attn_bias, scale) as called by diffusers

@@ -32,6 +32,8 @@ SIGNATURES = {
                                    _vp]),
     "pgn_groupnorm_nhwc_workspace_bytes": (_c.c_size_t, [_i, _i, _i, _i]),
     "pgn_groupnorm_silu_nhwc": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _c.c_size_t, _vp]),
+    "pgn_groupnorm_silu_nhwc_cat": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp,
+                                         _c.c_size_t, _vp]),
     "pgn_softmax_rows": (_i, [_vp, _i64, _vp, _i, _i64, _i64, _i64, _f, _vp]),
     "pgn_geglu": (_i, [_vp, _vp, _i, _i64, _i, _i64, _i64, _vp]),
     "pgn_clip_scores": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp]),

@@ -19,7 +19,9 @@ namespace {
 constexpr int NH_MAX_THREADS = 1024;
 
 struct NhArgs {
-    const void* x;
+    const void* x;   // channels [0, C1)
+    const void* x2;  // channels [C1, C) of the same rows (channel concatenation read in place), or nullptr: C1 == C
+    int C1;
     void* y;
     const void* gamma;
     const void* beta;
@@ -61,9 +63,19 @@ __device__ __forceinline__ void nh_param8(const void* p, int dt, size_t i, float
     }
 }
 
+// a lane's 8 channels live in one of the two sources (C1 % 8 == 0): start of its column in sample n, and the row pitch
+__device__ __forceinline__ const unsigned short* nh_lane_src(const NhArgs& a, int n, int c, int* pitch) {
+    if (c < a.C1) {
+        *pitch = a.C1;
+        return reinterpret_cast<const unsigned short*>(a.x) + (size_t)n * a.HW * a.C1 + c;
+    }
+    *pitch = a.C - a.C1;
+    return reinterpret_cast<const unsigned short*>(a.x2) + (size_t)n * a.HW * (a.C - a.C1) + (c - a.C1);
+}
+
 template <int DT>
-__device__ __forceinline__ void nh_load8(const NhArgs& a, size_t elem, const float (&t)[8], bool has_add, float (&f)[8]) {
-    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(a.x) + elem);
+__device__ __forceinline__ void nh_load8(const unsigned short* p, const float (&t)[8], bool has_add, float (&f)[8]) {
+    const u16x8_t v = *reinterpret_cast<const u16x8_t*>(p);
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = Cvt<DT>::to_f32(v[j]);
     if (has_add) {
@@ -84,16 +96,16 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArg
     const int t = threadIdx.x;
     const int r = t / a.C8, cc = t - r * a.C8;
     const bool active = r < a.R;
-    const size_t img = (size_t)n * a.HW * a.C;
     const bool has_add = a.addnc != nullptr;
     float tadd[8], piv[8], s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { tadd[j] = 0.f; piv[j] = 0.f; s[j] = 0.f; q[j] = 0.f; }
     if (active) {
         if (has_add) nh_param8(a.addnc, a.add_dt, (size_t)n * a.C + cc * 8, 0.f, tadd);
-        nh_load8<DT>(a, img + (size_t)cc * 8, tadd, has_add, piv);   // row 0 of the sample: one pivot per channel
+        int pitch;
+        const unsigned short* xp = nh_lane_src(a, n, cc * 8, &pitch);
+        nh_load8<DT>(xp, tadd, has_add, piv);   // row 0 of the sample: one pivot per channel
         const int row1 = min(a.HW, (sc + 1) * a.rows);
-        const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x) + img + (size_t)cc * 8;
         auto accum = [&](const u16x8_t& v) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -107,13 +119,13 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArg
         int row = sc * a.rows + r;
         // four independent 16-byte loads in flight per lane (a lane's rows are R rows apart)
         for (; row + 3 * a.R < row1; row += 4 * a.R) {
-            const u16x8_t v0 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)row * a.C);
-            const u16x8_t v1 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(row + a.R) * a.C);
-            const u16x8_t v2 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(row + 2 * a.R) * a.C);
-            const u16x8_t v3 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(row + 3 * a.R) * a.C);
+            const u16x8_t v0 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)row * pitch);
+            const u16x8_t v1 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(row + a.R) * pitch);
+            const u16x8_t v2 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(row + 2 * a.R) * pitch);
+            const u16x8_t v3 = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(row + 3 * a.R) * pitch);
             accum(v0); accum(v1); accum(v2); accum(v3);
         }
-        for (; row < row1; row += a.R) accum(*reinterpret_cast<const u16x8_t*>(xp + (size_t)row * a.C));
+        for (; row < row1; row += a.R) accum(*reinterpret_cast<const u16x8_t*>(xp + (size_t)row * pitch));
 #pragma unroll
         for (int j = 0; j < 8; ++j) sh[(size_t)r * a.C + cc * 8 + j] = make_float2(s[j], q[j]);
     }
@@ -140,7 +152,8 @@ __global__ __launch_bounds__(64) void pgn_gn_nhwc_finalize_kernel(NhArgs a) {
     const int c0 = g * a.cpg + lane, c1 = c0 + 64;
     const bool v0 = lane < a.cpg, v1 = lane + 64 < a.cpg;
     auto pivot = [&](int c) {
-        float p = Cvt<DT>::to_f32(reinterpret_cast<const unsigned short*>(a.x)[(size_t)n * a.HW * a.C + c]);
+        int pitch;
+        float p = Cvt<DT>::to_f32(*nh_lane_src(a, n, c, &pitch));
         if (a.addnc != nullptr)
             p = Cvt<DT>::to_f32(Cvt<DT>::from_f32(p + nh_param(a.addnc, a.add_dt, (size_t)n * a.C + c, 0.f)));
         return p;
@@ -194,7 +207,8 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArg
     }
     const int row1 = min(a.HW, (sc + 1) * a.rows);
     unsigned short* yp = reinterpret_cast<unsigned short*>(a.y);
-    const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x);
+    int pitch;
+    const unsigned short* xp = nh_lane_src(a, n, cc * 8, &pitch);
     auto apply = [&](const u16x8_t& v, size_t e) {
         u16x8_t o;
 #pragma unroll
@@ -209,15 +223,16 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArg
     int row = sc * a.rows + r;
     for (; row + 3 * a.R < row1; row += 4 * a.R) {
         const size_t e0 = img + (size_t)row * a.C + cc * 8, st = (size_t)a.R * a.C;
-        const u16x8_t v0 = *reinterpret_cast<const u16x8_t*>(xp + e0);
-        const u16x8_t v1 = *reinterpret_cast<const u16x8_t*>(xp + e0 + st);
-        const u16x8_t v2 = *reinterpret_cast<const u16x8_t*>(xp + e0 + 2 * st);
-        const u16x8_t v3 = *reinterpret_cast<const u16x8_t*>(xp + e0 + 3 * st);
+        const size_t i0 = (size_t)row * pitch, si = (size_t)a.R * pitch;
+        const u16x8_t v0 = *reinterpret_cast<const u16x8_t*>(xp + i0);
+        const u16x8_t v1 = *reinterpret_cast<const u16x8_t*>(xp + i0 + si);
+        const u16x8_t v2 = *reinterpret_cast<const u16x8_t*>(xp + i0 + 2 * si);
+        const u16x8_t v3 = *reinterpret_cast<const u16x8_t*>(xp + i0 + 3 * si);
         apply(v0, e0); apply(v1, e0 + st); apply(v2, e0 + 2 * st); apply(v3, e0 + 3 * st);
     }
     for (; row < row1; row += a.R) {
         const size_t e = img + (size_t)row * a.C + cc * 8;
-        apply(*reinterpret_cast<const u16x8_t*>(xp + e), e);
+        apply(*reinterpret_cast<const u16x8_t*>(xp + (size_t)row * pitch), e);
     }
 }
 
@@ -257,10 +272,13 @@ extern "C" size_t pgn_groupnorm_nhwc_workspace_bytes(int N, int C, int HW, int G
     return ((size_t)N * a.S * C + (size_t)N * G) * sizeof(float2);
 }
 
-extern "C" int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const void* gamma, const void* beta,
-                                       int affine_dtype, const void* add_nc, int add_dtype, int N, int C, int HW, int G,
-                                       float eps, int act, void* workspace, size_t workspace_bytes, void* stream) {
+static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, const void* gamma, const void* beta,
+                  int affine_dtype, const void* add_nc, int add_dtype, int N, int C, int HW, int G,
+                  float eps, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (x == nullptr || y == nullptr || workspace == nullptr) return PGN_ERR_INVALID;
+    if (C1 <= 0 || C1 > C || (C1 < C) != (x2 != nullptr)) return PGN_ERR_INVALID;
+    if ((C1 & 7) != 0) return PGN_ERR_UNSUPPORTED;
+    if (x2 != nullptr && !pgn_aligned(x2, 16)) return PGN_ERR_INVALID;
     if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return PGN_ERR_INVALID;
     if ((gamma == nullptr) != (beta == nullptr)) return PGN_ERR_INVALID;
     if (gamma != nullptr && pgn_dtype_size(affine_dtype) == 0) return PGN_ERR_INVALID;
@@ -277,7 +295,7 @@ extern "C" int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const 
         return PGN_ERR_INVALID;
     const size_t need = ((size_t)N * a.S * C + (size_t)N * G) * sizeof(float2);
     if (workspace_bytes < need) return PGN_ERR_INVALID;
-    a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.addnc = add_nc; a.adt = affine_dtype; a.add_dt = add_dtype;
+    a.x = x; a.x2 = x2; a.C1 = C1; a.y = y; a.gamma = gamma; a.beta = beta; a.addnc = add_nc; a.adt = affine_dtype; a.add_dt = add_dtype;
     a.eps = eps; a.act = act;
     a.part = (float2*)workspace;
     a.stats = a.part + (size_t)N * a.S * C;
@@ -296,4 +314,21 @@ extern "C" int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const 
     }
     PGN_LAUNCH_CHECK();
     return PGN_OK;
+}
+
+extern "C" int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const void* gamma, const void* beta,
+                                       int affine_dtype, const void* add_nc, int add_dtype, int N, int C, int HW, int G,
+                                       float eps, int act, void* workspace, size_t workspace_bytes, void* stream) {
+    return nh_run(x, C, nullptr, y, dtype, gamma, beta, affine_dtype, add_nc, add_dtype, N, C, HW, G, eps, act,
+                  workspace, workspace_bytes, stream);
+}
+
+extern "C" int pgn_groupnorm_silu_nhwc_cat(const void* x1, int C1, const void* x2, int C2, void* y, int dtype,
+                                           const void* gamma, const void* beta, int affine_dtype, const void* add_nc,
+                                           int add_dtype, int N, int HW, int G, float eps, int act, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    if (x2 == nullptr || C1 <= 0 || C2 <= 0) return PGN_ERR_INVALID;
+    if ((C2 & 7) != 0) return PGN_ERR_UNSUPPORTED;
+    return nh_run(x1, C1, x2, y, dtype, gamma, beta, affine_dtype, add_nc, add_dtype, N, C1 + C2, HW, G, eps, act,
+                  workspace, workspace_bytes, stream);
 }

@@ -80,6 +80,15 @@ def conv2d_bias(conv: nn.Conv2d, x: torch.Tensor, residual: Optional[torch.Tenso
     return ops.bias_residual_add(y, conv.bias, residual)
 
 
+# PGN_SPLIT_CONCAT=0: the up blocks write torch.cat([hidden, skip]) and the 1x1 shortcuts stay MIOpen convolutions
+SPLIT_CONCAT = os.environ.get("PGN_SPLIT_CONCAT", "1") != "0"
+
+
+def _nhwc_rows(x: torch.Tensor) -> torch.Tensor:
+    """[N*H*W, C] view of a channels_last activation."""
+    return x.permute(0, 2, 3, 1).view(-1, x.shape[1])
+
+
 class ResnetBlock2D(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, temb_channels: Optional[int], groups: int = 32,
                  eps: float = 1e-5, output_scale_factor: float = 1.0):
@@ -92,11 +101,35 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
         self.output_scale_factor = output_scale_factor
 
-    def forward(self, input_tensor, temb=None):
+    def _gemm_shortcut_ok(self, x: torch.Tensor, skip: Optional[torch.Tensor]) -> bool:
+        sc = self.conv_shortcut
+        ok = (SPLIT_CONCAT and sc is not None and sc.kernel_size == (1, 1) and sc.stride == (1, 1) and sc.groups == 1
+              and sc.padding == (0, 0) and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)
+              and sc.weight.dtype == x.dtype and ops._is_channels_last(x) and _bias_fusable(self.conv2, x)
+              and x.shape[1] % 8 == 0 and x.shape[1] // self.norm1.num_groups <= 128)
+        if ok and skip is not None:
+            c = x.shape[1] + skip.shape[1]
+            ok = (ops._is_channels_last(skip) and skip.dtype == x.dtype and skip.shape[1] % 8 == 0
+                  and c == self.norm1.num_channels and c // self.norm1.num_groups <= 128 and c <= 8192)
+        return ok
+
+    def forward(self, input_tensor, temb=None, skip=None):
         """diffusers ResnetBlock2D.forward.  Three broadcast / tensor adds never run as launches of their own:
         conv1's bias and the time-embedding projection travel as ONE per-(sample, channel) vector into norm2's
-        kernel; conv2's bias (+ the shortcut's) and the residual add are one pgn_bias_residual_add launch."""
-        x = self.norm1(input_tensor)
+        kernel; conv2's bias (+ the shortcut's) and the residual add are one pgn_bias_residual_add launch.
+
+        skip: the up blocks' `torch.cat([hidden_states, res_hidden_states], dim=1)` handed over as its two halves
+        (input_tensor, skip).  On the GPU in channels_last the concatenation is never written: norm1 reads both
+        halves in place (ops.group_norm_silu_cat) and the 1x1 shortcut is two GEMMs over the halves, accumulated
+        (beta = 1) into conv2's output; a 1x1 shortcut on a single input is one such GEMM."""
+        gemm_sc = self._gemm_shortcut_ok(input_tensor, skip)
+        if skip is not None and not gemm_sc:
+            input_tensor, skip = torch.cat([input_tensor, skip], dim=1), None
+        if skip is not None:
+            x = ops.group_norm_silu_cat(input_tensor, skip, self.norm1.num_groups, self.norm1.weight, self.norm1.bias,
+                                        self.norm1.eps, silu=self.norm1.act)
+        else:
+            x = self.norm1(input_tensor)
         t = None
         if self.time_emb_proj is not None and temb is not None:
             t = self.time_emb_proj(F.silu(temb))   # [N, C]: its broadcast add is fused into norm2's kernel
@@ -108,6 +141,18 @@ class ResnetBlock2D(nn.Module):
         h = self.norm2(h, add_nc=t)
         if self.conv_shortcut is None:
             out = conv2d_bias(self.conv2, h, input_tensor)
+        elif gemm_sc:
+            hh = _conv_nobias(self.conv2, h)
+            if not ops._is_channels_last(hh):
+                hh = hh.contiguous(memory_format=torch.channels_last)
+            w = self.conv_shortcut.weight.flatten(1)           # [C_out, C_in]
+            c1 = input_tensor.shape[1]
+            rows = _nhwc_rows(hh)
+            rows.addmm_(_nhwc_rows(input_tensor), w[:, :c1].t())
+            if skip is not None:
+                rows.addmm_(_nhwc_rows(skip), w[:, c1:].t())
+            b = (self.conv2.bias.float() + self.conv_shortcut.bias.float()).to(hh.dtype)
+            out = ops.bias_residual_add(hh, b, None)
         elif _bias_fusable(self.conv2, h):
             # both biases in one vector: shortcut(x) + b_s + conv2(h) + b_2
             sc = _conv_nobias(self.conv_shortcut, input_tensor)

@@ -257,10 +257,30 @@ def group_norm_silu(x: torch.Tensor, num_groups: int, weight: Optional[torch.Ten
     return y
 
 
-def _group_norm_silu_nhwc(x, num_groups, weight, bias, eps, silu, add_nc):
+def _is_channels_last(x: torch.Tensor) -> bool:
+    return x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)    # dense [N, H, W, C] memory
+
+
+def group_norm_silu_cat(x1: torch.Tensor, x2: torch.Tensor, num_groups: int, weight: Optional[torch.Tensor],
+                        bias: Optional[torch.Tensor], eps: float = 1e-5, silu: bool = True) -> torch.Tensor:
+    """group_norm_silu(torch.cat([x1, x2], dim=1)) for two channels_last activations, without writing the concatenation
+    (pgn_groupnorm_silu_nhwc_cat; bit-identical to the two-step form).  Returns a channels_last tensor."""
+    _dev(x1, x2, weight, bias)
+    if (x1.dim() != 4 or x2.dim() != 4 or x1.shape[0] != x2.shape[0] or x1.shape[2:] != x2.shape[2:]
+            or x1.dtype != x2.dtype):
+        raise ValueError("group_norm_silu_cat expects two [N, C_i, H, W] tensors of one dtype and spatial shape")
+    if x1.dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError("group_norm_silu_cat: bf16 / fp16 only")
+    if not (_is_channels_last(x1) and _is_channels_last(x2)):
+        raise ValueError("group_norm_silu_cat expects channels_last tensors")
+    return _group_norm_silu_nhwc(x1, num_groups, weight, bias, eps, silu, None, x2=x2)
+
+
+def _group_norm_silu_nhwc(x, num_groups, weight, bias, eps, silu, add_nc, x2=None):
     """channels_last input -> channels_last output through pgn_groupnorm_silu_nhwc (no layout change, no copy)."""
     lib = _lib.load()
-    N, C, H, W = x.shape
+    N, C1, H, W = x.shape
+    C = C1 + (x2.shape[1] if x2 is not None else 0)
     HW = H * W
     if (weight is None) != (bias is None):
         raise ValueError("weight and bias must both be given or both be None")
@@ -276,17 +296,25 @@ def _group_norm_silu_nhwc(x, num_groups, weight, bias, eps, silu, add_nc):
             raise ValueError("add_nc must be [N, C]")
         add_nc = add_nc.contiguous()
         add_dt = _dt(add_nc)
-    y = torch.empty_like(x)     # preserves the channels_last strides
+    if x2 is None:
+        y = torch.empty_like(x)     # preserves the channels_last strides
+    else:
+        y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     ws_bytes = int(lib.pgn_groupnorm_nhwc_workspace_bytes(N, C, HW, int(num_groups)))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=x.device)
 
     def run():
-        rc = lib.pgn_groupnorm_silu_nhwc(_ptr(x), _ptr(y), _dt(x), _ptr(weight), _ptr(bias), adt, _ptr(add_nc), add_dt,
-                                         N, C, HW, int(num_groups), float(eps), 1 if silu else 0, _ptr(ws), ws_bytes,
-                                         _stream())
+        if x2 is None:
+            rc = lib.pgn_groupnorm_silu_nhwc(_ptr(x), _ptr(y), _dt(x), _ptr(weight), _ptr(bias), adt, _ptr(add_nc),
+                                             add_dt, N, C, HW, int(num_groups), float(eps), 1 if silu else 0, _ptr(ws),
+                                             ws_bytes, _stream())
+        else:
+            rc = lib.pgn_groupnorm_silu_nhwc_cat(_ptr(x), C1, _ptr(x2), C - C1, _ptr(y), _dt(x), _ptr(weight),
+                                                 _ptr(bias), adt, _ptr(add_nc), add_dt, N, HW, int(num_groups),
+                                                 float(eps), 1 if silu else 0, _ptr(ws), ws_bytes, _stream())
         _lib.check(rc, "pgn_groupnorm_silu_nhwc")
 
-    _launch("groupnorm_silu" if silu else "groupnorm", float(2 * x.numel() * x.element_size()), run)
+    _launch("groupnorm_silu" if silu else "groupnorm", float(2 * y.numel() * y.element_size()), run)
     return y
 
 

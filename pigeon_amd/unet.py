@@ -280,7 +280,7 @@ class _UpBlock(nn.Module):
         for i, resnet in enumerate(self.resnets):
             res = res_samples[-1]
             res_samples = res_samples[:-1]
-            hidden_states = resnet(torch.cat([hidden_states, res], dim=1), temb)
+            hidden_states = resnet(hidden_states, temb, skip=res)
             if self.attentions is not None:
                 hidden_states = self.attentions[i](hidden_states, encoder_hidden_states, encoder_attention_mask)
         if self.upsamplers is not None:

@@ -66,6 +66,13 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 1, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 1, None, 0, None) == -1
     assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 1, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 1, p16, 8, None) == -1
     assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 0, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 1, p16, 1 << 20, None) == -2
+    # concatenation form: second source mandatory, halves in multiples of 8 channels
+    cat = lib.pgn_groupnorm_silu_nhwc_cat
+    assert cat(p16, 32, None, 32, p16, 1, None, None, 1, None, 0, 1, 16, 32, 1e-5, 1, p16, 1 << 20, None) == -1
+    assert cat(p16, 32, p16, 0, p16, 1, None, None, 1, None, 0, 1, 16, 32, 1e-5, 1, p16, 1 << 20, None) == -1
+    assert cat(p16, 36, p16, 28, p16, 1, None, None, 1, None, 0, 1, 16, 32, 1e-5, 1, p16, 1 << 20, None) == -2
+    assert cat(p16, 32, p16 + 2, 32, p16, 1, None, None, 1, None, 0, 1, 16, 32, 1e-5, 1, p16, 1 << 20, None) == -1
+    assert cat(p16, 32, p16, 32, p16, 1, None, None, 1, None, 0, 1, 16, 32, 1e-5, 1, p16, 8, None) == -1   # workspace
     # row kernels: nulls -> invalid; D / C not a multiple of 8, fp32 io, C > 4096 -> unsupported
     assert lib.pgn_bias_residual_add(p16, None, p16, 1, p16, 1, 2, 12, 1, None) == -2      # C % 8 with inner 1
     assert lib.pgn_bias_residual_add(p16, None, p16, 1, p16, 1, 2, 8, 9, None) == -2       # inner % 8

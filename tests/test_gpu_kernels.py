@@ -497,6 +497,42 @@ def test_groupnorm_channels_last_matches_oracle(ops, case):
     assert torch.equal(got, again)     # no atomics: run-to-run bit-identical
 
 
+CAT_CASES = [(2, 1280, 1280, 32, 32), (2, 1280, 640, 32, 32), (1, 640, 320, 64, 64), (2, 320, 320, 38, 26),
+             (3, 40, 24, 5, 3), (1, 8, 248, 1, 1)]
+
+
+@pytest.mark.parametrize("case", CAT_CASES, ids=[f"{c[1]}+{c[2]}x{c[3]}x{c[4]}" for c in CAT_CASES])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_groupnorm_over_an_unwritten_concatenation(ops, case, dtype):
+    # the up blocks' torch.cat([hidden, skip], dim=1) + norm1: both halves read in place; groups straddle the boundary
+    # in the 1280+640 / 640+320 / 40+24 cases (60, 30, 2 channels per group).  Same partial sums in the same order as
+    # the one-source kernel on the materialised concatenation -> bit-identical to it, and within the oracle's bar
+    N, C1, C2, H, W = case
+    g = torch.Generator().manual_seed(C1 + C2 + H)
+    x1 = (torch.randn(N, C1, H, W, generator=g) * 1.5 + torch.randn(1, C1, 1, 1, generator=g)).to(dtype)
+    x2 = (torch.randn(N, C2, H, W, generator=g) * 0.7 - 0.5).to(dtype)
+    C = C1 + C2
+    w = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype)
+    b = (0.2 * torch.randn(C, generator=g)).to(dtype)
+    d1 = x1.to(DEV).contiguous(memory_format=torch.channels_last)
+    d2 = x2.to(DEV).contiguous(memory_format=torch.channels_last)
+    for silu in (True, False):
+        got = ops.group_norm_silu_cat(d1, d2, 32 if C % 32 == 0 else 8, w.to(DEV), b.to(DEV), 1e-5, silu)
+        cat = torch.cat([d1, d2], dim=1).contiguous(memory_format=torch.channels_last)
+        two_step = ops.group_norm_silu(cat, 32 if C % 32 == 0 else 8, w.to(DEV), b.to(DEV), 1e-5, silu)
+        assert got.shape == (N, C, H, W) and torch.equal(got, two_step)
+        if H * W > 1:
+            assert got.is_contiguous(memory_format=torch.channels_last)
+        want = ops_ref.group_norm_silu_ref(torch.cat([x1, x2], dim=1), 32 if C % 32 == 0 else 8, w, b, 1e-5, silu)
+        err = (got.cpu().float() - want.float()).abs()
+        ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+        assert bool((err <= ulp * want.float().abs() + 4 * ulp * 2.0 ** -7 + 1e-6).all()), err.max().item()
+    with pytest.raises(ValueError):
+        ops.group_norm_silu_cat(d1, d2.contiguous() if H * W > 1 and C2 > 1 else d2[:, :, :0], 32, None, None)
+    with pytest.raises(ValueError):
+        ops.group_norm_silu_cat(d1, d2[:1].expand(N + 1, -1, -1, -1), 32, None, None)
+
+
 @pytest.mark.parametrize("shape", [(2, 320, 16, 24), (3, 64, 5, 7), (1, 1280, 8, 8), (2, 8, 1, 3)])
 @pytest.mark.parametrize("with_res", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
