@@ -167,6 +167,13 @@ int pgn_groupnorm_silu_nhwc_cat(const void* x1, int C1, const void* x2, int C2, 
                                 const void* beta, int affine_dtype, const void* add_nc, int add_dtype, int N, int HW,
                                 int G, float eps, int act, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Nearest-neighbour 2x upsampling of a CHANNELS-LAST activation: x [N, H, W, C] -> y [N, 2H, 2W, C],
+ * y[n, 2h+dy, 2w+dx, :] = x[n, h, w, :].  Replaces `F.interpolate(hidden_states, scale_factor=2.0, mode="nearest")` of
+ * diffusers Upsample2D.forward (models/upsampling.py), reached from `self.unet(...)` lavit_for_pigeon.py:752-757 (two
+ * per forward) and `self.vae.decode(...)` :774 (three per image).  Pure data movement (bit-exact); bf16 / f16,
+ * C % 8 == 0, x != y.  Algorithmic bytes: N*H*W*C * 2 * (1 + 4). */
+int pgn_upsample_nearest2x_nhwc(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-head attention forward, softmax(q k^T * scale + key_bias) v, flash-style on MFMA.
  * Replaces xformers.ops.memory_efficient_attention(q, k, v, attn_bias, scale) as called by diffusers

@@ -34,6 +34,7 @@ SIGNATURES = {
     "pgn_groupnorm_silu_nhwc": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _c.c_size_t, _vp]),
     "pgn_groupnorm_silu_nhwc_cat": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp,
                                          _c.c_size_t, _vp]),
+    "pgn_upsample_nearest2x_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pgn_softmax_rows": (_i, [_vp, _i64, _vp, _i, _i64, _i64, _i64, _f, _vp]),
     "pgn_geglu": (_i, [_vp, _vp, _i, _i64, _i, _i64, _i64, _vp]),
     "pgn_clip_scores": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp]),

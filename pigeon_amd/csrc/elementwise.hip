@@ -242,6 +242,36 @@ __global__ __launch_bounds__(EW_THREADS) void pgn_image_u8_kernel(const void* __
     }
 }
 
+// ---- nearest-neighbour 2x upsampling, channels-last ---------------------------------------------------------------
+// y[n, 2h+dy, 2w+dx, :] = x[n, h, w, :].  One workgroup per (input row, segment): a lane reads 16 bytes once and
+// stores them four times; the (pixel, chunk) pair is advanced without a division.  Pure data movement: any 16-bit type.
+__global__ __launch_bounds__(EW_THREADS) void pgn_upsample2x_cl_kernel(const unsigned short* __restrict__ x,
+                                                                        unsigned short* __restrict__ y, int H, int W,
+                                                                        int C8, int per_seg) {
+    const long long row = blockIdx.x;                 // n * H + h
+    const int n = (int)(row / H), h = (int)(row - (long long)n * H);
+    const int chunks = W * C8;
+    const int i0 = blockIdx.y * per_seg, i1 = min(chunks, i0 + per_seg);
+    const size_t C = (size_t)C8 * 8;
+    const unsigned short* xr = x + (size_t)row * W * C;
+    unsigned short* y0 = y + ((size_t)n * 2 * H + 2 * h) * (2 * (size_t)W) * C;
+    unsigned short* y1 = y0 + 2 * (size_t)W * C;
+    int i = i0 + (int)threadIdx.x;
+    int w = i / C8, c = i - w * C8;
+    const int dw = EW_THREADS / C8, dc = EW_THREADS - dw * C8;
+    for (; i < i1; i += EW_THREADS) {
+        const u16x8_t v = *reinterpret_cast<const u16x8_t*>(xr + (size_t)i * 8);
+        const size_t o = (size_t)w * 2 * C + (size_t)c * 8;
+        *reinterpret_cast<u16x8_t*>(y0 + o) = v;
+        *reinterpret_cast<u16x8_t*>(y0 + o + C) = v;
+        *reinterpret_cast<u16x8_t*>(y1 + o) = v;
+        *reinterpret_cast<u16x8_t*>(y1 + o + C) = v;
+        w += dw;
+        c += dc;
+        if (c >= C8) { c -= C8; ++w; }
+    }
+}
+
 }  // namespace
 
 extern "C" int pgn_geglu(const void* h, void* y, int dtype, int64_t M, int D, int64_t ld_h, int64_t ld_y,
@@ -377,6 +407,27 @@ extern "C" int pgn_bias_residual_add(const void* x, const void* residual, const 
     if (dtype == PGN_BF16) PGN_BR_D(PGN_BF16);
     else PGN_BR_D(PGN_F16);
 #undef PGN_BR_D
+    PGN_LAUNCH_CHECK();
+    return PGN_OK;
+}
+
+extern "C" int pgn_upsample_nearest2x_nhwc(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream) {
+    if (x == nullptr || y == nullptr || x == y) return PGN_ERR_INVALID;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return PGN_ERR_INVALID;
+    if (dtype != PGN_BF16 && dtype != PGN_F16) return PGN_ERR_UNSUPPORTED;
+    if ((C % 8) != 0) return PGN_ERR_UNSUPPORTED;
+    if (!pgn_aligned(x, 16) || !pgn_aligned(y, 16)) return PGN_ERR_INVALID;
+    const long long rows = (long long)N * H, chunks = (long long)W * (C / 8);
+    if (rows > 0x7fffffffLL || chunks > 0x7fffffffLL) return PGN_ERR_UNSUPPORTED;
+    // ~2048 workgroups per launch, each at least one pass of the block over its segment
+    long long segs = (2048 + rows - 1) / rows;
+    const long long max_segs = (chunks + EW_THREADS - 1) / EW_THREADS;
+    if (segs > max_segs) segs = max_segs;
+    if (segs > 65535) segs = 65535;
+    if (segs < 1) segs = 1;
+    const int per_seg = (int)((chunks + segs - 1) / segs);
+    hipLaunchKernelGGL(pgn_upsample2x_cl_kernel, dim3((unsigned)rows, (unsigned)segs), dim3(EW_THREADS), 0,
+                       (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, H, W, C / 8, per_seg);
     PGN_LAUNCH_CHECK();
     return PGN_OK;
 }

@@ -180,14 +180,21 @@ class Downsample2D(nn.Module):
         return conv2d_bias(self.conv, x)
 
 
+HIP_UPSAMPLE = os.environ.get("PGN_HIP_UPSAMPLE", "1") != "0"
+
+
 class Upsample2D(nn.Module):
     def __init__(self, channels: int):
         super().__init__()
         self.conv = nn.Conv2d(channels, channels, 3, padding=1)
 
     def forward(self, x, output_size=None):
-        if output_size is None:
-            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        if output_size is None or tuple(output_size) == (2 * x.shape[2], 2 * x.shape[3]):
+            if (HIP_UPSAMPLE and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.shape[1] % 8 == 0
+                    and x.numel() and ops._is_channels_last(x)):
+                x = ops.upsample_nearest2x(x)      # torch's channels_last kernel runs at 0.7 TB/s
+            else:
+                x = F.interpolate(x, scale_factor=2.0, mode="nearest")
         else:
             x = F.interpolate(x, size=output_size, mode="nearest")
         return conv2d_bias(self.conv, x)

@@ -318,6 +318,26 @@ def _group_norm_silu_nhwc(x, num_groups, weight, bias, eps, silu, add_nc, x2=Non
     return y
 
 
+def upsample_nearest2x(x: torch.Tensor) -> torch.Tensor:
+    """F.interpolate(x, scale_factor=2.0, mode="nearest") for a channels_last [N, C, H, W] activation (bf16 / fp16,
+    C % 8 == 0), through pgn_upsample_nearest2x_nhwc; returns a channels_last tensor."""
+    lib = _lib.load()
+    _dev(x)
+    if not _is_channels_last(x):
+        raise ValueError("upsample_nearest2x expects a channels_last [N, C, H, W] tensor")
+    if x.dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError("upsample_nearest2x: bf16 / fp16 only")
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+
+    def run():
+        rc = lib.pgn_upsample_nearest2x_nhwc(_ptr(x), _ptr(y), _dt(x), N, H, W, C, _stream())
+        _lib.check(rc, "pgn_upsample_nearest2x_nhwc")
+
+    _launch("upsample", float(5 * x.numel() * x.element_size()), run)
+    return y
+
+
 # ------------------------------------------------------------------------------------------------
 def geglu(h: torch.Tensor) -> torch.Tensor:
     """hidden * gelu(gate) with [hidden | gate] = h.chunk(2, dim=-1) (diffusers GEGLU.forward) in one launch."""

@@ -73,6 +73,10 @@ def test_argument_validation_happens_before_any_launch():
     assert cat(p16, 36, p16, 28, p16, 1, None, None, 1, None, 0, 1, 16, 32, 1e-5, 1, p16, 1 << 20, None) == -2
     assert cat(p16, 32, p16 + 2, 32, p16, 1, None, None, 1, None, 0, 1, 16, 32, 1e-5, 1, p16, 1 << 20, None) == -1
     assert cat(p16, 32, p16, 32, p16, 1, None, None, 1, None, 0, 1, 16, 32, 1e-5, 1, p16, 8, None) == -1   # workspace
+    assert lib.pgn_upsample_nearest2x_nhwc(p16, p16, 1, 1, 2, 2, 8, None) == -1            # in place is refused
+    assert lib.pgn_upsample_nearest2x_nhwc(p16, p16 + 64, 1, 1, 2, 2, 12, None) == -2      # C % 8
+    assert lib.pgn_upsample_nearest2x_nhwc(p16, p16 + 64, 0, 1, 2, 2, 8, None) == -2       # fp32
+    assert lib.pgn_upsample_nearest2x_nhwc(p16, p16 + 64, 1, 0, 2, 2, 8, None) == -1
     # row kernels: nulls -> invalid; D / C not a multiple of 8, fp32 io, C > 4096 -> unsupported
     assert lib.pgn_bias_residual_add(p16, None, p16, 1, p16, 1, 2, 12, 1, None) == -2      # C % 8 with inner 1
     assert lib.pgn_bias_residual_add(p16, None, p16, 1, p16, 1, 2, 8, 9, None) == -2       # inner % 8

@@ -497,6 +497,25 @@ def test_groupnorm_channels_last_matches_oracle(ops, case):
     assert torch.equal(got, again)     # no atomics: run-to-run bit-identical
 
 
+@pytest.mark.parametrize("shape", [(2, 1280, 32, 32), (1, 640, 64, 64), (3, 40, 5, 3), (1, 2560, 3, 7), (2, 8, 1, 1),
+                                   (1, 512, 128, 128), (1, 24, 1, 300)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_upsample_nearest2x_channels_last_is_bit_exact(ops, shape, dtype):
+    # diffusers Upsample2D.forward: F.interpolate(x, scale_factor=2.0, mode="nearest"); pure data movement
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).to(dtype)
+    want = torch.nn.functional.interpolate(x.float(), scale_factor=2.0, mode="nearest").to(dtype)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    got = ops.upsample_nearest2x(xd)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got.cpu(), want)
+    if shape[1] > 1 and shape[2] * shape[3] > 1:
+        with pytest.raises(ValueError):
+            ops.upsample_nearest2x(x.to(DEV))          # NCHW memory
+    with pytest.raises(TypeError):
+        ops.upsample_nearest2x(xd.float())
+
+
 CAT_CASES = [(2, 1280, 1280, 32, 32), (2, 1280, 640, 32, 32), (1, 640, 320, 64, 64), (2, 320, 320, 38, 26),
              (3, 40, 24, 5, 3), (1, 8, 248, 1, 1)]
 
