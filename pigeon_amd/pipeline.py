@@ -65,6 +65,9 @@ class PigeonPixelDecoder:
         # cross-attention skips the all-zero unconditional rows (see HipAttnProcessor.zero_ctx_rows)
         self.skip_zero_context = os.environ.get("PGN_SKIP_ZERO_CONTEXT", "1") != "0"
         self.use_hip_graph = os.environ.get("PGN_HIP_GRAPH", "0") == "1"      # see enable_hip_graph
+        # cross-attention K / V are projections of encoder_hidden_states alone, which the loop never changes: compute
+        # them at the first denoising step of a call and reuse them for the others (dropped when the call returns)
+        self.reuse_cross_kv = os.environ.get("PGN_REUSE_CROSS_KV", "1") != "0"
         self._graphs = {}
         if pixel_decoding == "lowres":
             if uncond_embeddings is None:
@@ -177,6 +180,7 @@ class PigeonPixelDecoder:
         zero_rows = batch_size if (self.skip_zero_context and hasattr(self.unet, "set_zero_context_rows")) else 0
         if zero_rows:
             self.unet.set_zero_context_rows(zero_rows)
+        kv_before = self._begin_cross_kv_reuse()
         try:
             if self.use_hip_graph and callback is None:
                 latents = self._denoise_graphed(latents, input_embeds, added_cond_kwargs, host_timesteps,
@@ -188,6 +192,7 @@ class PigeonPixelDecoder:
                     if callback is not None:
                         callback(i, t, latents)
         finally:
+            self._end_cross_kv_reuse(kv_before)
             if zero_rows:
                 self.unet.set_zero_context_rows(0)
 
@@ -195,6 +200,18 @@ class PigeonPixelDecoder:
             return latents, prompt_embeds, pooled_prompt_embeds
         images = self.decode_latents(latents, output_type)
         return images, prompt_embeds, pooled_prompt_embeds
+
+    def _begin_cross_kv_reuse(self):
+        """Switch the UNet's processors to K / V reuse for one denoising loop; returns what _end_cross_kv_reuse needs."""
+        if not (self.reuse_cross_kv and hasattr(self.unet, "enable_cross_kv_cache")):
+            return None
+        before = bool(getattr(self.unet, "cross_kv_cache_enabled", False))
+        self.unet.enable_cross_kv_cache(True)          # also drops anything cached by an earlier call
+        return before
+
+    def _end_cross_kv_reuse(self, before):
+        if before is not None:
+            self.unet.enable_cross_kv_cache(before)    # resets every processor's cache: nothing outlives the call
 
     def _denoise_step(self, latents, t_host, t_unet, input_embeds, added_cond_kwargs, guidance):
         """One iteration of :744-764: three fused launches around the UNet forward."""
@@ -233,6 +250,8 @@ class PigeonPixelDecoder:
                 self._denoise_step(st["lat"], host_timesteps[0], t_dev[0], st["emb"], added, guidance)
             torch.cuda.current_stream(self.device).wait_stream(side)
             self._reset_scheduler_cursor()
+            if getattr(self.unet, "cross_kv_cache_enabled", False):
+                self.unet.enable_cross_kv_cache(True)   # drop the warm-up's K / V: the capture must hold its own
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 x = st["lat"]
@@ -284,13 +303,17 @@ class PigeonPixelDecoder:
             raise ValueError(f"latents must have shape {shape}")
         latents = (latents.float() * self.scheduler.init_noise_sigma).to(self.device)          # :861-862
         self.scheduler.set_timesteps(num_inference_steps, device=self.device)                  # :864
-        for i, t in enumerate(list(self.scheduler._host_timesteps)):                           # :866
-            latent_model_input = ops.cfg_expand_scale(latents, self.unet.dtype, self.scheduler.scale_divisor(t))
-            noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings,
-                                   encoder_attention_mask=text_embeddings_mask).sample          # :873-874
-            latents = self.scheduler.step_cfg(noise_pred, t, latents, guidance_scale_for_decoder).prev_sample
-            if callback is not None:
-                callback(i, t, latents)
+        kv_before = self._begin_cross_kv_reuse()
+        try:
+            for i, t in enumerate(list(self.scheduler._host_timesteps)):                       # :866
+                latent_model_input = ops.cfg_expand_scale(latents, self.unet.dtype, self.scheduler.scale_divisor(t))
+                noise_pred = self.unet(latent_model_input, t, encoder_hidden_states=text_embeddings,
+                                       encoder_attention_mask=text_embeddings_mask).sample      # :873-874
+                latents = self.scheduler.step_cfg(noise_pred, t, latents, guidance_scale_for_decoder).prev_sample
+                if callback is not None:
+                    callback(i, t, latents)
+        finally:
+            self._end_cross_kv_reuse(kv_before)
         if output_type == "latent":
             return latents, xrec
         # :883-884 run inside the autocast region: the division is fp32, the first convolution casts to bf16

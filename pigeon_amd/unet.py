@@ -392,6 +392,9 @@ class UNet2DConditionModel(nn.Module):
                 m.processor.reset_cache()     # cached cross K/V hold the rows of the previous mode
 
     def enable_cross_kv_cache(self, enabled: bool = True):
+        """Cross-attention K / V are kept per processor and reused while the SAME encoder_hidden_states tensor object
+        comes in (a denoising loop); every call of this method drops what is cached."""
+        self.cross_kv_cache_enabled = bool(enabled)
         for m in self.modules():
             if isinstance(m, Attention) and isinstance(m.processor, HipAttnProcessor):
                 m.processor.cache_cross_kv = enabled

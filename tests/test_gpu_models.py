@@ -367,6 +367,32 @@ def test_zero_context_rows_shortcut_changes_nothing(stack):
     assert all(p.zero_ctx_rows == 0 for p in unet.attn_processors.values() if isinstance(p, HipAttnProcessor))
 
 
+def test_cross_kv_reuse_inside_a_denoising_loop_changes_nothing(stack):
+    # K / V of cross-attention are projections of encoder_hidden_states alone: generate_image computes them at the
+    # first step and reuses them (PGN_REUSE_CROSS_KV); same GEMMs on the same inputs -> bit-identical latents, and
+    # nothing stays cached after the call
+    from pigeon_amd.attention_processor import HipAttnProcessor
+    pipe = stack["pipe"]
+    assert pipe.reuse_cross_kv
+    kw = dict(width=128, height=128, num_inference_steps=3, guidance_scale_for_diffusion=7.0, output_type="latent")
+    toks = weights.synth_tokens(2, seed=31)
+    noise = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(6)).to(DEV)
+    hits = []
+    procs = [p for p in pipe.unet.attn_processors.values() if isinstance(p, HipAttnProcessor)]
+    reused = pipe.generate_image(image_tokens=toks, latents=noise, callback=lambda i, t, x: hits.append(
+        sum(p._kv_cache is not None for p in procs)), **kw)[0]
+    assert hits[0] > 0 and hits == [hits[0]] * 3          # every cross-attention layer holds its K / V during the loop
+    assert all(p._kv_cache is None and not p.cache_cross_kv for p in procs)
+    pipe.reuse_cross_kv = False
+    try:
+        plain = pipe.generate_image(image_tokens=toks, latents=noise, **kw)[0]
+    finally:
+        pipe.reuse_cross_kv = True
+    assert torch.equal(reused, plain)
+    other = pipe.generate_image(image_tokens=weights.synth_tokens(2, seed=32), latents=noise, **kw)[0]
+    assert _rel(other, reused)[1] > 0.05                   # a new call projects its own context
+
+
 def test_fused_qkv_projection_equals_separate_projections(stack, monkeypatch):
     # self-attention runs to_q / to_k / to_v as one GEMM over the concatenated weights (HipAttnProcessor._self_qkv):
     # each element is the same dot product, so the result equals three separate GEMMs up to tile selection; the
