@@ -141,50 +141,61 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArg
     }
 }
 
-// one wavefront per (sample, group)
+// one 256-thread workgroup per (sample, group): thread -> (chunk lane, channel of the group); the chunk lanes split the S
+// row chunks, LDS brings them together, threads [0, cpg) finish their channel in a fixed order
+constexpr int NH_FIN_THREADS = 256;
+
+__device__ __forceinline__ float nh_fin_block_sum(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();                                   // red may still be read from the previous sum
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < NH_FIN_THREADS / 64; ++w) r += red[w];
+    return r;
+}
+
 template <int DT>
-__global__ __launch_bounds__(64) void pgn_gn_nhwc_finalize_kernel(NhArgs a) {
+__global__ __launch_bounds__(NH_FIN_THREADS) void pgn_gn_nhwc_finalize_kernel(NhArgs a) {
+    __shared__ float2 sh[NH_FIN_THREADS];
+    __shared__ float red[NH_FIN_THREADS / 64];
     const int n = blockIdx.x / a.G, g = blockIdx.x % a.G;
-    const int lane = threadIdx.x;
+    const int t = threadIdx.x;
     const float hw = (float)a.HW;
-    // pass 1: per-channel totals (channels lane, lane + 64 of the group), then the group mean
-    float S0 = 0.f, Q0 = 0.f, p0 = 0.f, S1 = 0.f, Q1 = 0.f, p1 = 0.f;
-    const int c0 = g * a.cpg + lane, c1 = c0 + 64;
-    const bool v0 = lane < a.cpg, v1 = lane + 64 < a.cpg;
-    auto pivot = [&](int c) {
-        int pitch;
-        float p = Cvt<DT>::to_f32(*nh_lane_src(a, n, c, &pitch));
-        if (a.addnc != nullptr)
-            p = Cvt<DT>::to_f32(Cvt<DT>::from_f32(p + nh_param(a.addnc, a.add_dt, (size_t)n * a.C + c, 0.f)));
-        return p;
-    };
+    const int L = NH_FIN_THREADS / a.cpg;              // cpg <= 128: at least two chunk lanes
+    const int ls = t / a.cpg, cl = t - ls * a.cpg;
+    float s = 0.f, q = 0.f;
+    if (ls < L) {
+        const float2* p = a.part + (size_t)n * a.S * a.C + (size_t)g * a.cpg + cl;
+        for (int sc = ls; sc < a.S; sc += L) {
+            const float2 v = p[(size_t)sc * a.C];
+            s += v.x;
+            q += v.y;
+        }
+    }
+    sh[t] = make_float2(s, q);
+    __syncthreads();
+    const bool v0 = t < a.cpg;
+    float S0 = 0.f, Q0 = 0.f, p0 = 0.f;
     if (v0) {
-        p0 = pivot(c0);
-        for (int sc = 0; sc < a.S; ++sc) {
-            const float2 v = a.part[((size_t)n * a.S + sc) * a.C + c0];
+        for (int l = 0; l < L; ++l) {
+            const float2 v = sh[l * a.cpg + t];
             S0 += v.x;
             Q0 += v.y;
         }
+        const int c = g * a.cpg + t;
+        int pitch;
+        p0 = Cvt<DT>::to_f32(*nh_lane_src(a, n, c, &pitch));      // per-channel pivot: row 0 of the sample
+        if (a.addnc != nullptr)
+            p0 = Cvt<DT>::to_f32(Cvt<DT>::from_f32(p0 + nh_param(a.addnc, a.add_dt, (size_t)n * a.C + c, 0.f)));
     }
-    if (v1) {
-        p1 = pivot(c1);
-        for (int sc = 0; sc < a.S; ++sc) {
-            const float2 v = a.part[((size_t)n * a.S + sc) * a.C + c1];
-            S1 += v.x;
-            Q1 += v.y;
-        }
-    }
-    float m = (v0 ? p0 + S0 / hw : 0.f) + (v1 ? p1 + S1 / hw : 0.f);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off);
-    const float mean = m / (float)a.cpg;
+    const float mean = nh_fin_block_sum(v0 ? p0 + S0 / hw : 0.f, red) / (float)a.cpg;
     float var = 0.f;
-    if (v0) { const float d = p0 - mean; var += Q0 + 2.f * d * S0 + hw * d * d; }
-    if (v1) { const float d = p1 - mean; var += Q1 + 2.f * d * S1 + hw * d * d; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off);
-    var = fmaxf(var / ((float)a.cpg * hw), 0.f);
-    if (lane == 0) a.stats[(size_t)n * a.G + g] = make_float2(mean, 1.0f / sqrtf(var + a.eps));
+    if (v0) { const float d = p0 - mean; var = Q0 + 2.f * d * S0 + hw * d * d; }
+    var = fmaxf(nh_fin_block_sum(var, red) / ((float)a.cpg * hw), 0.f);
+    if (t == 0) a.stats[(size_t)n * a.G + g] = make_float2(mean, 1.0f / sqrtf(var + a.eps));
 }
 
 template <int DT>
@@ -250,7 +261,7 @@ static bool nh_geometry(int N, int C, int HW, int G, NhArgs* a) {
     a->R = R;
     long long target = g_nh_target_wgs / N;      // ~8 workgroups per CU over the whole launch
     if (target < 1) target = 1;
-    if (target > 64) target = 64;
+    if (target > 1024) target = 1024;
     long long rows = (HW + target - 1) / target;
     if (rows < (long long)g_nh_min_rows_per_lane * R) rows = (long long)g_nh_min_rows_per_lane * R;   // amortise the LDS reduction
     if (rows > HW) rows = HW;
@@ -305,11 +316,11 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
     const dim3 grid((unsigned)(N * a.S)), block(threads);
     if (dtype == PGN_BF16) {
         hipLaunchKernelGGL((pgn_gn_nhwc_stats_kernel<PGN_BF16>), grid, block, lds, s, a);
-        hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<PGN_BF16>), dim3(N * G), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<PGN_BF16>), dim3(N * G), dim3(NH_FIN_THREADS), 0, s, a);
         hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<PGN_BF16>), grid, block, 0, s, a);
     } else {
         hipLaunchKernelGGL((pgn_gn_nhwc_stats_kernel<PGN_F16>), grid, block, lds, s, a);
-        hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<PGN_F16>), dim3(N * G), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<PGN_F16>), dim3(N * G), dim3(NH_FIN_THREADS), 0, s, a);
         hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<PGN_F16>), grid, block, 0, s, a);
     }
     PGN_LAUNCH_CHECK();
