@@ -47,7 +47,9 @@ class HipAttnProcessor:
         q, k, v = attn.to_q, attn.to_k, attn.to_v
         if not (_FUSE_QKV and hs.is_cuda and hs.dtype in (torch.bfloat16, torch.float16)
                 and q.bias is None and k.bias is None and v.bias is None
-                and q.weight.shape == k.weight.shape == v.weight.shape and q.weight.dtype == hs.dtype):
+                and q.weight.shape == k.weight.shape == v.weight.shape and q.weight.dtype == hs.dtype
+                and not (torch.is_grad_enabled() and (q.weight.requires_grad or k.weight.requires_grad
+                                                      or v.weight.requires_grad))):   # the fused copy is detached
             return q(hs), k(hs), v(hs)
         key = tuple((w.data_ptr(), w._version) for w in (q.weight, k.weight, v.weight))
         cached = getattr(attn, "_qkv_fused", None)

@@ -399,6 +399,9 @@ def test_fused_qkv_projection_equals_separate_projections(stack, monkeypatch):
     # fused weight follows the parameters (in-place writes and replaced storage both rebuild it)
     from pigeon_amd import attention_processor as ap
     attn = ap.Attention(128, heads=2, dim_head=64).to(DEV, torch.bfloat16)
+    attn(torch.zeros(1, 8, 128, device=DEV, dtype=torch.bfloat16))
+    assert not hasattr(attn, "_qkv_fused")        # trainable weights with autograd on: separate projections
+    attn.requires_grad_(False)
     g = torch.Generator().manual_seed(21)
     hs = torch.randn(3, 80, 128, generator=g).to(DEV, torch.bfloat16)
     fused = attn(hs)
