@@ -136,57 +136,80 @@ __global__ __launch_bounds__(EW_THREADS) void pgn_bias_res_nchw_kernel(const uns
     }
 }
 
-// One wavefront per row, R vectors of 8 elements per lane held in registers (C <= 512 * R).
-template <int DT, int R, bool HAS_RES>
+// One wavefront per NR consecutive rows, R vectors of 8 elements per lane and row held in registers (C <= 512 * R).
+// NR = 2 doubles the bytes a wavefront has in flight: narrow rows (C = 640: 80 of 128 lane slots) are latency-bound
+// with one row per wavefront.  Rows are independent: the arithmetic per row does not depend on NR.
+template <int DT, int R, bool HAS_RES, int NR>
 __global__ __launch_bounds__(EW_THREADS) void pgn_add_layernorm_kernel(
     const unsigned short* __restrict__ x, const unsigned short* __restrict__ res, unsigned short* __restrict__ sum_out,
     unsigned short* __restrict__ y, const void* __restrict__ gamma, const void* __restrict__ beta, int adt, long long M,
     int C, float eps, const float* __restrict__ cb) {
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * (EW_THREADS / 64) + (threadIdx.x >> 6);
-    if (row >= M) return;   // whole wavefront leaves together: no barrier in this kernel
+    const long long row0 = ((long long)blockIdx.x * (EW_THREADS / 64) + (threadIdx.x >> 6)) * NR;
+    if (row0 >= M) return;   // whole wavefront leaves together: no barrier in this kernel
     const int C8 = C >> 3;
-    const unsigned short* xr = x + row * C;
-    float f[R][8];
-    float s = 0.f;
+    u16x8_t raw[NR][R], rraw[NR][R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int v = lane + 64 * r;
-        if (v < C8) {
-            unpack8<DT>(*reinterpret_cast<const u16x8_t*>(xr + 8 * v), f[r]);
-            if (cb != nullptr) {   // pending per-channel bias of bias-free GEMMs accumulated into x (uniform branch)
-                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cb + 8 * v);
-                const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cb + 8 * v + 4);
+    for (int n = 0; n < NR; ++n) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { f[r][j] += lo[j]; f[r][4 + j] += hi[j]; }
+        for (int r = 0; r < R; ++r) {
+            const int v = lane + 64 * r;
+            if (v < C8 && row0 + n < M) {
+                raw[n][r] = *reinterpret_cast<const u16x8_t*>(x + (row0 + n) * C + 8 * v);
+                if constexpr (HAS_RES) rraw[n][r] = *reinterpret_cast<const u16x8_t*>(res + (row0 + n) * C + 8 * v);
             }
-            if constexpr (HAS_RES) {
-                float g[8];
-                unpack8<DT>(*reinterpret_cast<const u16x8_t*>(res + row * C + 8 * v), g);
+        }
+    }
+    float f[NR][R][8];
+    float s[NR];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[r][j] += g[j];   // one fp32 add, rounded below: torch's bf16 add
-                const u16x8_t hv = pack8<DT>(f[r]);
-                *reinterpret_cast<u16x8_t*>(sum_out + row * C + 8 * v) = hv;
-                unpack8<DT>(hv, f[r]);                          // the norm sees the rounded sum, as in the reference
+    for (int n = 0; n < NR; ++n) {
+        s[n] = 0.f;
+        const long long row = row0 + n;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int v = lane + 64 * r;
+            if (v < C8 && row < M) {
+                unpack8<DT>(raw[n][r], f[n][r]);
+                if (cb != nullptr) {   // pending per-channel bias of bias-free GEMMs accumulated into x (uniform branch)
+                    const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cb + 8 * v);
+                    const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cb + 8 * v + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { f[n][r][j] += lo[j]; f[n][r][4 + j] += hi[j]; }
+                }
+                if constexpr (HAS_RES) {
+                    float g[8];
+                    unpack8<DT>(rraw[n][r], g);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[n][r][j] += g[j];   // one fp32 add, rounded below: torch's bf16 add
+                    const u16x8_t hv = pack8<DT>(f[n][r]);
+                    *reinterpret_cast<u16x8_t*>(sum_out + row * C + 8 * v) = hv;
+                    unpack8<DT>(hv, f[n][r]);                          // the norm sees the rounded sum, as in the reference
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[n] += f[n][r][j];
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += f[r][j];
         }
     }
     const float inv_c = 1.0f / (float)C;
-    const float mean = wave_sum64(s) * inv_c;
-    float q = 0.f;
+    float mean[NR], rstd[NR];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (lane + 64 * r < C8) {
+    for (int n = 0; n < NR; ++n) mean[n] = wave_sum64(s[n]) * inv_c;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = f[r][j] - mean;
-                q += d * d;
+    for (int n = 0; n < NR; ++n) {
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (lane + 64 * r < C8 && row0 + n < M) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = f[n][r][j] - mean[n];
+                    q += d * d;
+                }
             }
         }
+        rstd[n] = 1.0f / sqrtf(wave_sum64(q) * inv_c + eps);
     }
-    const float rstd = 1.0f / sqrtf(wave_sum64(q) * inv_c + eps);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int v = lane + 64 * r;
@@ -206,8 +229,13 @@ __global__ __launch_bounds__(EW_THREADS) void pgn_add_layernorm_kernel(
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[r][j] = (f[r][j] - mean) * rstd * ga[j] + be[j];
-            *reinterpret_cast<u16x8_t*>(y + row * C + 8 * v) = pack8<DT>(f[r]);
+            for (int n = 0; n < NR; ++n) {
+                if (row0 + n < M) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[n][r][j] = (f[n][r][j] - mean[n]) * rstd[n] * ga[j] + be[j];
+                    *reinterpret_cast<u16x8_t*>(y + (row0 + n) * C + 8 * v) = pack8<DT>(f[n][r]);
+                }
+            }
         }
     }
 }
@@ -296,6 +324,9 @@ extern "C" int pgn_geglu(const void* h, void* y, int dtype, int64_t M, int D, in
     return PGN_OK;
 }
 
+int g_ln_rows2_max_r = 2;   // measured: C = 640 95 -> 78 us, C = 320 216 -> 162 us at 131 k / 524 k rows; C = 1280 (3 vectors per lane) loses 7 %
+extern "C" void pgn_layernorm_tuning(int rows2_max_r) { g_ln_rows2_max_r = rows2_max_r; }
+
 extern "C" int pgn_add_layernorm(const void* x, const void* residual, void* sum_out, void* y, const void* gamma,
                                  const void* beta, int dtype, int affine_dtype, int64_t M, int C, float eps,
                                  void* stream) {
@@ -315,23 +346,26 @@ extern "C" int pgn_add_layernorm_cb(const void* x, const void* residual, void* s
     if ((C & 7) != 0 || C > 4096) return PGN_ERR_UNSUPPORTED;
     if (!pgn_aligned(x, 16) || !pgn_aligned(y, 16) || !pgn_aligned(residual, 16) || !pgn_aligned(sum_out, 16))
         return PGN_ERR_UNSUPPORTED;
-    const long long blocks = (M + (EW_THREADS / 64) - 1) / (EW_THREADS / 64);
+    const int r = (C / 8 + 63) / 64;   // vectors per lane: 1..8
+    // two rows per wavefront where rows are narrow and plentiful (g_ln_rows2_max_r: tuning hook, not part of the ABI)
+    const int nr = (r <= g_ln_rows2_max_r && M >= 16384) ? 2 : 1;
+    const long long rows_per_block = (long long)(EW_THREADS / 64) * nr;
+    const long long blocks = (M + rows_per_block - 1) / rows_per_block;
     if (blocks > 0x7fffffffLL) return PGN_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), block(EW_THREADS);
-    const int r = (C / 8 + 63) / 64;   // vectors per lane: 1..8
-#define PGN_LN_LAUNCH(DT, R, RES)                                                                             \
-    hipLaunchKernelGGL((pgn_add_layernorm_kernel<DT, R, RES>), grid, block, 0, s, (const unsigned short*)x,    \
+#define PGN_LN_LAUNCH(DT, R, RES, NR)                                                                         \
+    hipLaunchKernelGGL((pgn_add_layernorm_kernel<DT, R, RES, NR>), grid, block, 0, s, (const unsigned short*)x, \
                        (const unsigned short*)residual, (unsigned short*)sum_out, (unsigned short*)y, gamma,  \
                        beta, affine_dtype, (long long)M, C, eps, col_bias)
 #define PGN_LN_R(DT, RES)                       \
     do {                                        \
-        if (r <= 1) PGN_LN_LAUNCH(DT, 1, RES);  \
-        else if (r <= 2) PGN_LN_LAUNCH(DT, 2, RES); \
-        else if (r <= 3) PGN_LN_LAUNCH(DT, 3, RES); \
-        else if (r <= 4) PGN_LN_LAUNCH(DT, 4, RES); \
-        else if (r <= 6) PGN_LN_LAUNCH(DT, 6, RES); \
-        else PGN_LN_LAUNCH(DT, 8, RES);         \
+        if (r <= 1) { if (nr == 2) PGN_LN_LAUNCH(DT, 1, RES, 2); else PGN_LN_LAUNCH(DT, 1, RES, 1); }      \
+        else if (r <= 2) { if (nr == 2) PGN_LN_LAUNCH(DT, 2, RES, 2); else PGN_LN_LAUNCH(DT, 2, RES, 1); } \
+        else if (r <= 3) { if (nr == 2) PGN_LN_LAUNCH(DT, 3, RES, 2); else PGN_LN_LAUNCH(DT, 3, RES, 1); } \
+        else if (r <= 4) PGN_LN_LAUNCH(DT, 4, RES, 1); \
+        else if (r <= 6) PGN_LN_LAUNCH(DT, 6, RES, 1); \
+        else PGN_LN_LAUNCH(DT, 8, RES, 1);         \
     } while (0)
     if (dtype == PGN_BF16) {
         if (residual) PGN_LN_R(PGN_BF16, true);
