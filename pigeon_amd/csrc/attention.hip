@@ -389,8 +389,9 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     if (key_bias != nullptr && bias_sb < 0) return PGN_ERR_INVALID;
     // the kernel addresses a (batch, head) key / value slice with 32-bit byte offsets
     if (((int64_t)Nk + 2 * ATT_BN) * (k_sn > v_sn ? k_sn : v_sn) * 2 >= (int64_t)1 << 32) return PGN_ERR_UNSUPPORTED;
-    // Geometry: 4 waves x 32 rows, two workgroups per CU (2 waves per SIMD from DIFFERENT workgroups, so one
-    // workgroup's barrier / prologue / epilogue hides behind the other's main loop).  Measured on MI355X at every
+    // Geometry: 4 waves x 32 rows, three workgroups per CU at head dim 64 (two at 128, one at 256): the waves of a
+    // SIMD come from DIFFERENT workgroups, so one workgroup's barrier / prologue / epilogue hides behind the others'
+    // main loops.  Measured on MI355X at every
     // SDXL shape (scripts/bench_kernels.py): 4 waves beat the 8-wave 256-row geometry by 4 % (self, N 4096) to
     // 30 % (cross, Nk 256); the 8-wave form stays reachable through pgn_attention_tuning for A/B runs.
     int nw = 4;
