@@ -31,6 +31,7 @@ extern "C" {
 #define PGN_OK 0
 #define PGN_ERR_INVALID (-1)     /* null pointer, non-positive size, bad enum, misalignment */
 #define PGN_ERR_UNSUPPORTED (-2) /* valid request the gfx950 kernels do not cover (e.g. head_dim) */
+#define PGN_ERR_SCRATCH (-3)     /* pgn_groupnorm_silu_nhwc_static: the shape needs more than PGN_GN_STATIC_SCRATCH_BYTES */
 
 typedef enum { PGN_F32 = 0, PGN_BF16 = 1, PGN_F16 = 2 } pgn_dtype;
 
@@ -166,6 +167,21 @@ int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const void* gamma
 int pgn_groupnorm_silu_nhwc_cat(const void* x1, int C1, const void* x2, int C2, void* y, int dtype, const void* gamma,
                                 const void* beta, int affine_dtype, const void* add_nc, int add_dtype, int N, int HW,
                                 int G, float eps, int act, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Allocation-free variant of pgn_groupnorm_silu_nhwc.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot allocate device memory around the call — code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Same kernels, arithmetic and results (bit-identical) as pgn_groupnorm_silu_nhwc; the
+ * partial-statistics workspace is a static device array inside the library (PGN_GN_STATIC_SCRATCH_BYTES per GPU, held
+ * until the process ends) instead of caller memory, and the call path contains no hipMalloc / hipFree / allocating
+ * library routine.  The first call on a device resolves that device's copy of the array (hipGetSymbolAddress; make
+ * that call outside graph capture).  Shapes whose workspace (pgn_groupnorm_nhwc_workspace_bytes) exceeds
+ * PGN_GN_STATIC_SCRATCH_BYTES return PGN_ERR_SCRATCH before any launch (the workspace is about 768 * C * 8
+ * bytes whatever the batch: every shape with C <= 2560, i.e. the whole SDXL UNet and the VAE, fits).  All calls on one GPU share the array: calls that overlap on one GPU (two streams, two
+ * threads) race — serialise them on one stream.  Nothing in it has to start at zero. */
+#define PGN_GN_STATIC_SCRATCH_BYTES (16u << 20)
+int pgn_groupnorm_silu_nhwc_static(const void* x, void* y, int dtype, const void* gamma, const void* beta,
+                                   int affine_dtype, const void* add_nc, int add_dtype, int N, int C, int HW, int G,
+                                   float eps, int act, void* stream);
 
 /* Nearest-neighbour 2x upsampling of a CHANNELS-LAST activation: x [N, H, W, C] -> y [N, 2H, 2W, C],
  * y[n, 2h+dy, 2w+dx, :] = x[n, h, w, :].  Replaces `F.interpolate(hidden_states, scale_factor=2.0, mode="nearest")` of

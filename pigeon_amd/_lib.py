@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpigeon_hip.so")
 PGN_F32, PGN_BF16, PGN_F16 = 0, 1, 2
 PGN_PRED_EPSILON, PGN_PRED_SAMPLE, PGN_PRED_V = 0, 1, 2
 PGN_STEP_FUSED_FP32, PGN_STEP_CLIP_SAMPLE, PGN_STEP_USE_CLIPPED_OUTPUT = 1, 2, 4
-PGN_OK, PGN_ERR_INVALID, PGN_ERR_UNSUPPORTED = 0, -1, -2
+PGN_OK, PGN_ERR_INVALID, PGN_ERR_UNSUPPORTED, PGN_ERR_SCRATCH = 0, -1, -2, -3
+PGN_GN_STATIC_SCRATCH_BYTES = 16 << 20
 
 _c = ctypes
 _vp, _i, _i64, _f, _u = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint
@@ -32,6 +33,7 @@ SIGNATURES = {
                                    _vp]),
     "pgn_groupnorm_nhwc_workspace_bytes": (_c.c_size_t, [_i, _i, _i, _i]),
     "pgn_groupnorm_silu_nhwc": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _c.c_size_t, _vp]),
+    "pgn_groupnorm_silu_nhwc_static": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "pgn_groupnorm_silu_nhwc_cat": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp,
                                          _c.c_size_t, _vp]),
     "pgn_upsample_nearest2x_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -79,6 +81,8 @@ def check(code, what):
     msg = load().pgn_error_string(int(code)).decode()
     if code == PGN_ERR_UNSUPPORTED:
         raise NotImplementedError(f"{what}: {msg}")
+    if code == PGN_ERR_SCRATCH:
+        raise MemoryError(f"{what}: {msg}")
     if code == PGN_ERR_INVALID:
         raise ValueError(f"{what}: {msg}")
     raise PigeonHipError(f"{what}: HIP error {code}: {msg}")

@@ -7,6 +7,7 @@ extern "C" const char* pgn_error_string(int code) {
     if (code == PGN_OK) return "ok";
     if (code == PGN_ERR_INVALID) return "invalid argument (null pointer, bad size/enum or misaligned buffer)";
     if (code == PGN_ERR_UNSUPPORTED) return "request not covered by the gfx950 kernels";
+    if (code == PGN_ERR_SCRATCH) return "shape needs more scratch than the library's static device buffer holds";
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "unknown pigeon_hip error";
 }

@@ -14,6 +14,8 @@
 // smaller tensors), deterministic, no atomics.
 #include "pgn_common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int NH_MAX_THREADS = 1024;
@@ -342,4 +344,54 @@ extern "C" int pgn_groupnorm_silu_nhwc_cat(const void* x1, int C1, const void* x
     if ((C2 & 7) != 0) return PGN_ERR_UNSUPPORTED;
     return nh_run(x1, C1, x2, y, dtype, gamma, beta, affine_dtype, add_nc, add_dtype, N, C1 + C2, HW, G, eps, act,
                   workspace, workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Allocation-free variant (include/pigeon_hip.h: pgn_groupnorm_silu_nhwc_static).  The partial-statistics workspace the
+// three kernels exchange lives in a file-scope device array instead of caller memory, so the call path contains no
+// hipMalloc / hipFree / allocating library routine.  Every GPU the library runs on holds its own copy of the array at
+// its own address until the process ends; `scratch` below is only the host-side handle of the symbol, never a device
+// address: the per-device address is resolved once with hipGetSymbolAddress and only that pointer is handed to kernels.
+static __device__ __align__(256) unsigned char scratch[PGN_GN_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int NH_MAX_DEVICES = 64;
+void* g_scratch_dev_ptr[NH_MAX_DEVICES];   // device ordinal -> address of that device's copy of `scratch`
+std::mutex g_scratch_mu;
+
+// address of the current device's scratch array (resolved on the first call on that device, with it current)
+int nh_scratch_ptr(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= NH_MAX_DEVICES) return PGN_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_dev_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (p == nullptr) return (int)hipErrorInvalidSymbol;
+        g_scratch_dev_ptr[dev] = p;
+    }
+    *out = g_scratch_dev_ptr[dev];
+    return PGN_OK;
+}
+}  // namespace
+
+extern "C" int pgn_groupnorm_silu_nhwc_static(const void* x, void* y, int dtype, const void* gamma, const void* beta,
+                                              int affine_dtype, const void* add_nc, int add_dtype, int N, int C, int HW,
+                                              int G, float eps, int act, void* stream) {
+    if (x == nullptr || y == nullptr) return PGN_ERR_INVALID;
+    if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return PGN_ERR_INVALID;
+    NhArgs a;
+    if (!nh_geometry(N, C, HW, G, &a)) return PGN_ERR_UNSUPPORTED;
+    const size_t need = ((size_t)N * a.S * C + (size_t)N * G) * sizeof(float2);
+    if (need > (size_t)PGN_GN_STATIC_SCRATCH_BYTES) return PGN_ERR_SCRATCH;
+    void* ws = nullptr;
+    const int rc = nh_scratch_ptr(&ws);
+    if (rc != PGN_OK) return rc;
+    // every workspace word the finalize / apply launches read is written by the launch before it on the same stream:
+    // nothing has to start at zero, whatever the previous call left behind
+    return nh_run(x, C, nullptr, y, dtype, gamma, beta, affine_dtype, add_nc, add_dtype, N, C, HW, G, eps, act, ws,
+                  (size_t)PGN_GN_STATIC_SCRATCH_BYTES, stream);
 }
