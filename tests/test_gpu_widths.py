@@ -1,0 +1,245 @@
+"""Single modules at the REAL SDXL widths against the CPU oracle, with FIXED bars.
+
+test_gpu_models.py compares a tiny UNet (channels 64/128/128) with the oracle; the widths that carry the wall time
+(640 / 1280 channels, 10 / 20 heads of 64, 10-deep transformer stacks, the 1920->640 / 2560->1280 skip-concat resnets
+with GEMM shortcuts, the pending-bias chain of pigeon_amd/unet.py) are compared here, one module at a time so the fp32
+CPU oracle finishes in seconds.
+
+Protocol: weights and inputs are rounded to the 16-bit type once and given to both sides; the oracle evaluates them in
+fp32 (`Policy(torch.float32)`, oracle/models_ref.py - diffusers 0.27.2 semantics, PARITY UNPINNED by the reference,
+SURVEY 8(c)), the product in bf16 / fp16 through the HIP kernels.  The bar is a CONSTANT per module: relative L2 error
+of the output against the fp32 oracle.  Measured values (MI355X, round 2) are quoted beside each bar; the bars sit
+about 1.5x above them.  A systematic host-side error (a dropped bias, a wrong residual, a mis-ordered concat) is O(10 %)
+or more at these widths and far outside every bar; the fp16 runs (11-bit significands, 8x lower rounding floor) pin the
+host logic another order of magnitude tighter."""
+import importlib
+
+import pytest
+import torch
+
+from oracle import models_ref, weights
+from oracle.models_ref import SD, Policy
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F32 = Policy(torch.float32)
+
+
+def _rel(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return ((got - want).norm() / want.norm().clamp_min(1e-9)).item()
+
+
+def _rounded(sd, dtype):
+    return {k: v.to(dtype) for k, v in sd.items()}
+
+
+def _load(module, seed, dtype):
+    sd = _rounded(weights.synth_like(module, seed), dtype)
+    module.load_state_dict(sd)
+    return module.to(DEV, dtype).requires_grad_(False).eval(), SD({k: v.float() for k, v in sd.items()})
+
+
+def _check(got, want, bar, what):
+    e = _rel(got, want)
+    print(f"{what}: relL2 vs fp32 oracle {e:.5f} (bar {bar})")
+    assert torch.isfinite(got.float()).all()
+    assert e < bar, (what, e, bar)
+
+
+# (switch module, attribute) pairs: each restructuring switched off must meet the SAME bar (INTEGRATION.md switch table)
+BLOCK_SWITCHES = [None, ("pigeon_amd.unet", "ACCUMULATE_ATTENTION"), ("pigeon_amd.unet", "ACCUMULATE_FF"),
+                  ("pigeon_amd.attention_processor", "_FUSE_QKV")]
+RESNET_SWITCHES = [None, ("pigeon_amd.layers", "SPLIT_CONCAT"), ("pigeon_amd.layers", "FUSE_CONV_BIAS")]
+
+
+def _switch_off(monkeypatch, switch):
+    if switch is not None:
+        mod = importlib.import_module(switch[0])
+        assert getattr(mod, switch[1]) is True
+        monkeypatch.setattr(mod, switch[1], False)
+
+
+def _ids(vals):
+    return ["default" if v is None else v[1].lower().lstrip("_") + "=0" for v in vals]
+
+
+# ---- BasicTransformerBlock --------------------------------------------------------------------------------------
+# measured relL2 (bf16): 0.0044 at both widths and with every switch off; fp16: 0.00052-0.00055
+BLOCK_BAR = {torch.bfloat16: 0.007, torch.float16: 0.001}
+
+
+@pytest.mark.parametrize("switch", BLOCK_SWITCHES, ids=_ids(BLOCK_SWITCHES))
+@pytest.mark.parametrize("shape", [(1280, 20, 1024), (640, 10, 4096)], ids=["c1280-n1024", "c640-n4096"])
+def test_basic_transformer_block_at_sdxl_width(monkeypatch, shape, switch):
+    from pigeon_amd.unet import BasicTransformerBlock
+    C, heads, N = shape
+    _switch_off(monkeypatch, switch)
+    dt = torch.bfloat16
+    blk, sd = _load(BasicTransformerBlock(C, heads, 64, 2048), 31, dt)
+    g = torch.Generator().manual_seed(C + N)
+    x = torch.randn(2, N, C, generator=g).to(dt)
+    ctx = (torch.randn(2, 256, 2048, generator=g) * 0.6).to(dt)
+    got = blk(x.to(DEV), ctx.to(DEV))
+    want = models_ref.transformer_block(F32, sd, x.float(), ctx.float(), heads)
+    _check(got, want, BLOCK_BAR[dt], f"BasicTransformerBlock C={C} N={N} {switch}")
+
+
+def test_basic_transformer_block_fp16_and_zero_context_rows():
+    # fp16: same kernels, 8x lower rounding floor -> the host logic (pending biases, accumulate-in-place, fused qkv) is
+    # pinned to 0.1 %.  Then the CFG shortcut at real width: rows with an all-zero context skip cross-attention.
+    from pigeon_amd.attention_processor import HipAttnProcessor
+    from pigeon_amd.unet import BasicTransformerBlock
+    C, heads, N = 1280, 20, 1024
+    dt = torch.float16
+    blk, sd = _load(BasicTransformerBlock(C, heads, 64, 2048), 31, dt)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, N, C, generator=g).to(dt)
+    ctx = (torch.randn(2, 256, 2048, generator=g) * 0.6).to(dt)
+    want = models_ref.transformer_block(F32, sd, x.float(), ctx.float(), heads)
+    _check(blk(x.to(DEV), ctx.to(DEV)), want, BLOCK_BAR[dt], "BasicTransformerBlock fp16")
+    ctx[0] = 0
+    want0 = models_ref.transformer_block(F32, sd, x.float(), ctx.float(), heads)
+    for p in (blk.attn1.processor, blk.attn2.processor):
+        assert isinstance(p, HipAttnProcessor)
+        p.zero_ctx_rows = 1
+    _check(blk(x.to(DEV), ctx.to(DEV)), want0, BLOCK_BAR[dt], "BasicTransformerBlock fp16, zero-context row skipped")
+
+
+# ---- Transformer2DModel, 10 blocks: the pending-bias chain and proj_out's effective bias -------------------------
+# measured relL2 of (output - residual), i.e. of the transformer branch alone: bf16 0.0155-0.0160, fp16 0.0019-0.0020
+T2D_BAR = {torch.bfloat16: 0.019, torch.float16: 0.0026}
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("switch", [None, ("pigeon_amd.unet", "ACCUMULATE_ATTENTION")], ids=["default", "accumulate=0"])
+def test_transformer2d_ten_blocks_at_sdxl_width(monkeypatch, dt, switch):
+    from pigeon_amd.unet import Transformer2DModel
+    _switch_off(monkeypatch, switch)
+    C, heads, side = 1280, 20, 32
+    m, sd = _load(Transformer2DModel(heads, 64, C, 10, 2048, 32, True), 77, dt)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, C, side, side, generator=g).to(dt)
+    ctx = (torch.randn(2, 256, 2048, generator=g) * 0.6).to(dt)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    got = m(xd, ctx.to(DEV))
+    want = models_ref.transformer_2d(F32, sd, x.float(), ctx.float(), heads, 32)
+    assert got.shape == x.shape
+    # the residual passes through untouched: compare the branch the module adds
+    _check(got.float().cpu() - x.float(), want - x.float(), T2D_BAR[dt], f"Transformer2DModel x10 {dt} {switch}")
+
+
+# ---- up-block ResnetBlock2D over an unwritten concatenation, 1x1 shortcut as GEMMs -------------------------------
+# measured relL2: bf16 0.0030-0.0035, fp16 0.0004-0.0005
+RESNET_BAR = {torch.bfloat16: 0.005, torch.float16: 0.0007}
+
+
+@pytest.mark.parametrize("switch", RESNET_SWITCHES, ids=_ids(RESNET_SWITCHES))
+@pytest.mark.parametrize("shape", [(1280, 640, 640, 64), (1280, 1280, 1280, 32), (640, 320, 320, 64)],
+                         ids=["1920to640", "2560to1280", "960to320"])
+def test_up_block_resnet_with_skip_at_sdxl_width(monkeypatch, shape, switch):
+    from pigeon_amd.layers import ResnetBlock2D
+    c_hidden, c_skip, c_out, side = shape
+    _switch_off(monkeypatch, switch)
+    dt = torch.bfloat16
+    m, sd = _load(ResnetBlock2D(c_hidden + c_skip, c_out, 1280), 55, dt)
+    g = torch.Generator().manual_seed(c_out + side)
+    x = torch.randn(2, c_hidden, side, side, generator=g).to(dt)
+    skip = (torch.randn(2, c_skip, side, side, generator=g) * 1.3 + 0.1).to(dt)
+    temb = torch.randn(2, 1280, generator=g).to(dt)
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+    got = m(cl(x), temb.to(DEV), skip=cl(skip))
+    want = models_ref.resnet(F32, sd, torch.cat([x, skip], 1).float(), temb.float(), 32, 1e-5)
+    _check(got, want, RESNET_BAR[dt], f"ResnetBlock2D {c_hidden}+{c_skip}->{c_out} {switch}")
+
+
+def test_resnet_fp16_and_down_block_shortcut():
+    # fp16 bar on the concat form, and the down blocks' 320->640 resnet (1x1 shortcut on a single input, NCHW too)
+    from pigeon_amd.layers import ResnetBlock2D
+    dt = torch.float16
+    m, sd = _load(ResnetBlock2D(1920, 640, 1280), 55, dt)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 1280, 32, 32, generator=g).to(dt)
+    skip = torch.randn(2, 640, 32, 32, generator=g).to(dt)
+    temb = torch.randn(2, 1280, generator=g).to(dt)
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last)
+    want = models_ref.resnet(F32, sd, torch.cat([x, skip], 1).float(), temb.float(), 32, 1e-5)
+    _check(m(cl(x), temb.to(DEV), skip=cl(skip)), want, RESNET_BAR[dt], "ResnetBlock2D 1920->640 fp16")
+    _check(m(x.to(DEV), temb.to(DEV), skip=skip.to(DEV)), want, RESNET_BAR[dt], "ResnetBlock2D 1920->640 fp16 NCHW")
+    m, sd = _load(ResnetBlock2D(320, 640, 1280), 56, dt)
+    x = torch.randn(2, 320, 64, 64, generator=g).to(dt)
+    want = models_ref.resnet(F32, sd, x.float(), temb.float(), 32, 1e-5)
+    _check(m(cl(x), temb.to(DEV)), want, RESNET_BAR[dt], "ResnetBlock2D 320->640 fp16")
+
+
+# ---- the tiny UNet and generate_image in fp16: fixed bars an order below the bf16 caps of test_gpu_models.py -------
+# measured: UNet eps relL2 0.0019; latents after each of 4 guided steps 0.0034; images mean |d| 0.20 / 255, max 2
+UNET_FP16_BAR = 0.003
+LATENT_FP16_BAR = 0.006
+# the tiny stack of test_gpu_models.py
+TINY_UNET = dict(block_out_channels=(64, 128, 128), attention_head_dim=(1, 2, 2), transformer_layers_per_block=(1, 1, 2),
+                 cross_attention_dim=2048, layers_per_block=2, sample_size=16)
+TINY_VAE = dict(block_out_channels=(32, 64), layers_per_block=1, latent_channels=4, norm_num_groups=32,
+                scaling_factor=0.13025)
+SCHED = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000,
+             steps_offset=1, clip_sample=False, set_alpha_to_one=False, timestep_spacing="leading")
+
+
+@pytest.fixture(scope="module")
+def stack16():
+    from pigeon_amd.pipeline import PigeonPixelDecoder
+    from pigeon_amd.schedulers import DDIMScheduler
+    from pigeon_amd.token_decoder import HighresVQDecoder
+    from pigeon_amd.unet import UNet2DConditionModel
+    from pigeon_amd.vae import AutoencoderKL
+    dt = torch.float16
+    mods = dict(unet=UNet2DConditionModel(**TINY_UNET), dec=HighresVQDecoder(depth=2), vae=AutoencoderKL(**TINY_VAE))
+    sds = {}
+    for (k, m), seed in zip(mods.items(), (11, 123, 5)):
+        sds[k] = _rounded(weights.synth_like(m, seed), dt)
+        m.load_state_dict(sds[k])
+    codebook = weights.synth_codebook()
+    pipe = PigeonPixelDecoder(codebook, mods["dec"], mods["unet"], mods["vae"], DDIMScheduler(**SCHED), "fp16", DEV)
+    f32 = lambda sd: {k: v.float() for k, v in sd.items()}
+    return dict(pipe=pipe, sched=SCHED, codebook=codebook, unet_cfg=dict(mods["unet"].config),
+                vae_cfg=dict(mods["vae"].config), **{k + "_sd": f32(v) for k, v in sds.items()})
+
+
+def test_tiny_unet_fp16_fixed_bar(stack16):
+    st = stack16
+    g = torch.Generator().manual_seed(0)
+    h = lambda t: t.to(torch.float16)
+    x = h(torch.randn(4, 4, 20, 12, generator=g))
+    ctx = h(torch.randn(4, 256, 2048, generator=g) * 0.6)
+    pooled = h(torch.randn(4, 1280, generator=g) * 0.5)
+    ids = h(torch.tensor([[96.0, 160.0, 0, 0, 96.0, 160.0]])).repeat(4, 1)
+    got = st["pipe"].unet(x.to(DEV), 961, encoder_hidden_states=ctx.to(DEV),
+                          added_cond_kwargs={"text_embeds": pooled.to(DEV), "time_ids": ids.to(DEV)}).sample
+    want = models_ref.unet_forward(F32, st["unet_sd"], st["unet_cfg"], x.float(), torch.tensor(961), ctx.float(),
+                                   {"text_embeds": pooled.float(), "time_ids": ids.float()})
+    assert got.dtype == torch.float16
+    _check(got, want, UNET_FP16_BAR, "tiny UNet fp16")
+
+
+def test_generate_image_fp16_per_step_latents_fixed_bar(stack16):
+    import numpy as np
+    from oracle import pipeline_ref
+    st = stack16
+    tokens = weights.synth_tokens(2, seed=9)
+    k, steps, H, W = 2, 4, 128, 160
+    noise = torch.randn(2 * k, 4, H // 8, W // 8, generator=torch.Generator().manual_seed(123))
+    got_steps = []
+    images, _, _ = st["pipe"].generate_image(image_tokens=[t.to(DEV) for t in tokens], num_return_images=k, width=W,
+                                             height=H, num_inference_steps=steps, guidance_scale_for_diffusion=7.0,
+                                             latents=noise.to(DEV), output_type="uint8",
+                                             callback=lambda i, t, x: got_steps.append(x.cpu().clone()))
+    ref = pipeline_ref.generate_image_ref(F32, tokens, st["codebook"], st["dec_sd"], st["unet_sd"], st["unet_cfg"],
+                                          pipeline_ref.DDIMRef(**st["sched"]), noise, num_return_images=k, width=W,
+                                          height=H, num_inference_steps=steps, guidance_scale=7.0, vae_sd=st["vae_sd"],
+                                          vae_cfg=st["vae_cfg"])
+    assert len(got_steps) == steps
+    for i, (a, b) in enumerate(zip(got_steps, ref["latents_per_step"])):
+        _check(a, b, LATENT_FP16_BAR, f"fp16 latents after step {i}")
+    d = np.abs(images.cpu().numpy().astype(int) - ref["images"].astype(int))
+    print(f"fp16 images: mean |d| {d.mean():.3f} / 255, max {d.max()}")
+    assert d.mean() < 0.5 and d.max() <= 4
