@@ -238,7 +238,7 @@ int pgn_geglu(const void* h, void* y, int dtype, int64_t M, int D, int64_t ld_h,
 
 /* ---------------------------------------------------------------------------------------------
  * Scoring stage: per-image target score and history score from CLIP features.
- *   tgt_score[m]  = 100 * cos(img[m], txt[m])                          Evaluation/eval_utils.py:119-130
+ *   tgt_score[m]  = 100 * cos(img[m], txt[m])                          Evaluation/eval_utils.py:121-129
  *                   (CLIPScore.calculate_clip_score, called from cal_scores.py:160-165)
  *   hist_score[m] = mean_k 100 * cos(img[m], hist[m, k])               eval_utils.py:540-548 + the mean over the
  *                   5 history images of cal_scores.py:178-179

@@ -58,6 +58,23 @@ class DDIMRef:
         return ops_ref.ddim_step_ref(model_output, sample, a_t, a_prev, self.pred, clip, use_clipped_model_output)
 
 
+def threshold_sample_ref(sample: torch.Tensor, ratio: float, sample_max_value: float) -> torch.Tensor:
+    """diffusers 0.27.2 DDIMScheduler._threshold_sample ("dynamic thresholding", Imagen): per sample, s = the `ratio`
+    quantile of |x0| (linear interpolation between order statistics), clamped to [1, sample_max_value]; x0 is clipped
+    to [-s, s] and divided by s.  Restated with an explicit sort so it does not share torch.quantile with the product.
+    PARITY UNPINNED (third-party; not on the reference's default path: thresholding is off in SDXL's scheduler)."""
+    b = sample.shape[0]
+    flat = sample.double().reshape(b, -1)
+    a = np.sort(np.abs(flat.numpy()), axis=1)
+    n = a.shape[1]
+    pos = ratio * (n - 1)
+    lo, hi = int(math.floor(pos)), min(int(math.floor(pos)) + 1, n - 1)
+    s = a[:, lo] + (a[:, hi] - a[:, lo]) * (pos - lo)
+    s = np.clip(s, 1.0, sample_max_value)[:, None]
+    out = np.clip(flat.numpy(), -s, s) / s
+    return torch.from_numpy(out).reshape(sample.shape).to(sample.dtype)
+
+
 class EulerRef:
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  prediction_type="epsilon", timestep_spacing="linspace", steps_offset=0, **_):

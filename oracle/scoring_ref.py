@@ -1,6 +1,6 @@
 """Scoring-stage oracle (CPU).  TEST INFRASTRUCTURE ONLY.
 
-`clip_scores_ref` follows Evaluation/eval_utils.py:119-130 (CLIPScore.calculate_clip_score), :540-548
+`clip_scores_ref` follows Evaluation/eval_utils.py:121-129 (CLIPScore.calculate_clip_score), :540-548
 (evaluate_personalization_given_data_sim) and the mean over the 5 history images of Evaluation/cal_scores.py:178-179
 line by line.  `clip_vision_forward` restates open_clip's VisionTransformer.forward (`model.encode_image`, reached from
 eval_utils.py:120,541) over a plain state dict with open_clip's parameter names.  PARITY UNPINNED for the tower:

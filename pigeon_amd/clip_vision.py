@@ -208,28 +208,3 @@ class CLIPScorer:
         tgt, hist = ops.clip_scores(feats, tf, hf)
         nan = torch.full((feats.shape[0],), float("nan"), device=self.device)
         return torch.stack([nan if tgt is None else tgt, nan if hist is None else hist], dim=1)
-
-
-def build_select_scores(all_res: Dict, scores: torch.Tensor, num_return_sequences: int, num_return_images: int) -> Dict:
-    """The nested dict cal_scores.py:144-206 saves as `select_scores_dm_scale{g}.npy`:
-    select_scores[uid][target][genre][seq] = {"tgt_score": [one per image j], "hist_score": [...]}.
-    `scores` [M, 2] is ordered as the images were generated: task-major, then sequence, then image
-    (inference.py:447-448: index (i*nrs + seq)*nri + j over tasks i in all_res iteration order)."""
-    scores = scores.detach().float().cpu()
-    n_tasks = sum(len(all_res[u][t]) for u in all_res for t in all_res[u])
-    if n_tasks * num_return_sequences * num_return_images != scores.shape[0]:
-        raise ValueError("scores do not cover all_res")
-    out: Dict = {}
-    i = 0
-    for uid in all_res:
-        for tgt in all_res[uid]:
-            for genre in all_res[uid][tgt]:
-                slot = out.setdefault(uid, {}).setdefault(tgt, {}).setdefault(genre, {})
-                for seq in range(num_return_sequences):
-                    rec = slot[seq] = {"tgt_score": [], "hist_score": []}
-                    for j in range(num_return_images):
-                        row = scores[(i * num_return_sequences + seq) * num_return_images + j]
-                        rec["tgt_score"].append(float(row[0]))
-                        rec["hist_score"].append(float(row[1]))
-                i += 1
-    return out

@@ -1,5 +1,5 @@
 // Per-image preference / alignment scores of the scoring stage (see include/pigeon_hip.h: pgn_clip_scores).
-// Replaces, for one batch of CLIP image features, the arithmetic of Evaluation/eval_utils.py:119-130
+// Replaces, for one batch of CLIP image features, the arithmetic of Evaluation/eval_utils.py:121-129
 // (CLIPScore.calculate_clip_score: L2-normalise both sides, 100 * cosine similarity) and :540-548
 // (evaluate_personalization_given_data_sim against cached history features) together with the mean over the
 // 5 history images of Evaluation/cal_scores.py:178-179.  One wavefront per image: every feature row is read once,

@@ -397,7 +397,7 @@ def bias_residual_add(x: torch.Tensor, bias: torch.Tensor, residual: Optional[to
 def clip_scores(image_features: torch.Tensor, text_features: Optional[torch.Tensor] = None,
                 history_features: Optional[torch.Tensor] = None):
     """(tgt_score [M], hist_score [M]) fp32: 100*cos(image, text) and the mean over the history images of
-    100*cos(image, history) (Evaluation/eval_utils.py:119-130, 540-548; cal_scores.py:178-179).  Either may be None."""
+    100*cos(image, history) (Evaluation/eval_utils.py:121-129, 540-548; cal_scores.py:178-179).  Either may be None."""
     lib = _lib.load()
     _dev(image_features, text_features, history_features)
     if image_features.dim() != 2:

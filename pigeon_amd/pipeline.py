@@ -43,6 +43,8 @@ def numpy_to_pil(images: np.ndarray):
 class PigeonPixelDecoder:
     """Owns the frozen decoder stack (codebook, token decoder, UNet, scheduler, VAE) on one GPU."""
 
+    MAX_GRAPHS = 2      # captured denoising loops kept (least recently used dropped first)
+
     def __init__(self, codebook: torch.Tensor, tokenizer_decoder, unet, vae, scheduler=None,
                  model_dtype: str = "bf16", device: Union[str, torch.device] = "cuda", channels_last: bool = True,
                  pixel_decoding: str = "highres", uncond_embeddings: Optional[torch.Tensor] = None,
@@ -232,9 +234,14 @@ class PigeonPixelDecoder:
         return self
 
     def _denoise_graphed(self, latents, input_embeds, added_cond_kwargs, host_timesteps, guidance, zero_rows):
+        # everything the capture bakes in: shapes, the schedule, guidance, the scheduler OBJECT and its configuration
+        # (DDIM / Euler coefficients are launch constants), the UNet's dtype / device and parameter identity
+        sched_cfg = getattr(self.scheduler, "config", None)
         key = (tuple(latents.shape), tuple(input_embeds.shape), tuple(host_timesteps), float(guidance), zero_rows,
-               type(self.scheduler).__name__)
-        entry = self._graphs.get(key)
+               type(self.scheduler).__name__, id(self.scheduler),
+               repr(sorted(sched_cfg.items())) if hasattr(sched_cfg, "items") else None,
+               str(self.unet.dtype), str(self.unet.device), self.unet.conv_in.weight.data_ptr())
+        entry = self._graphs.pop(key, None)           # re-inserted below: dict order = least recently used first
         if entry is None:
             st = {"lat": latents.clone(), "emb": input_embeds.clone(),
                   "text": added_cond_kwargs["text_embeds"].clone(), "ids": added_cond_kwargs["time_ids"].clone()}
@@ -258,7 +265,10 @@ class PigeonPixelDecoder:
                 for t, td in zip(host_timesteps, t_dev):
                     x = self._denoise_step(x, t, td, st["emb"], added, guidance)
                 st["out"] = x
-            entry = self._graphs[key] = (graph, st, t_dev)
+            entry = (graph, st, t_dev)
+        self._graphs[key] = entry
+        while len(self._graphs) > self.MAX_GRAPHS:    # each entry pins a full activation pool
+            self._graphs.pop(next(iter(self._graphs)))
         graph, st, _ = entry
         st["lat"].copy_(latents)
         st["emb"].copy_(input_embeds)

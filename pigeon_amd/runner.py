@@ -5,7 +5,8 @@ Sharding: every (user, target) sample is independent end to end, so ranks take c
 sample list; full weight replica per GPU; no collective inside the denoising loop.  The one exchange step is an RCCL
 all-gather (torch.distributed backend "nccl" = RCCL over xGMI) of the final latents and per-image scores, once per
 outer batch.  Noise: every rank draws the GLOBAL noise tensor from an identically seeded generator and slices its rows,
-so an N-GPU run reproduces the 1-GPU run bit for bit.
+so an N-GPU run reproduces the 1-GPU run bit for bit (device generator for the highres decoder, host generator for the
+lowres one, as the reference draws them).
 """
 import math
 import os
@@ -31,26 +32,39 @@ def global_noise(shape: Sequence[int], seed: int, device, generator: Optional[to
 
 
 def all_gather_results(latents: torch.Tensor, scores: Optional[torch.Tensor], counts: Sequence[int], group=None):
-    """All-gather final latents [m_r, 4, h, w] (and scores [m_r, S]) from every rank; uneven tails are padded to
-    max(counts) rows for the collective and trimmed afterwards.  Works with backend nccl (RCCL) and gloo."""
+    """All-gather final latents [m_r, 4, h, w] (and scores [m_r, S]) from every rank in ONE collective: each image is
+    one fp32 row [4*h*w + S] (latents, then its scores), uneven tails are padded to max(counts) rows for the collective
+    and trimmed afterwards.  Works with backend nccl (RCCL over xGMI) and gloo.  Returns (latents, scores | None) in
+    global (rank-major = task) order, on the device the inputs live on."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return latents, scores
+    if latents.shape[0] != counts[dist.get_rank(group)] or (scores is not None and scores.shape[0] != latents.shape[0]):
+        raise ValueError("all_gather_results: row counts do not match this rank's entry of `counts`")
     m = max(counts)
-
+    dev = latents.device
+    lat_shape, n_lat = tuple(latents.shape[1:]), int(np.prod(latents.shape[1:]))
+    n_sc = 0 if scores is None else int(np.prod(scores.shape[1:]))
     host_staged = dist.get_backend(group) == "gloo"   # gloo collectives run on host memory
+    cdev = torch.device("cpu") if host_staged else dev
+    row = torch.zeros((m, n_lat + n_sc), dtype=torch.float32, device=cdev)
+    row[: latents.shape[0], :n_lat] = latents.reshape(latents.shape[0], n_lat).to(cdev, torch.float32)
+    if n_sc:
+        row[: scores.shape[0], n_lat:] = scores.reshape(scores.shape[0], n_sc).to(cdev, torch.float32)
+    out = torch.empty((world * m, n_lat + n_sc), dtype=torch.float32, device=cdev)
+    dist.all_gather_into_tensor(out, row, group=group)
+    rows = torch.cat([out[r * m: r * m + counts[r]] for r in range(world)], dim=0).to(dev)
+    g_lat = rows[:, :n_lat].reshape((rows.shape[0],) + lat_shape).to(latents.dtype)
+    g_sc = None if scores is None else rows[:, n_lat:].reshape((rows.shape[0],) + tuple(scores.shape[1:])).to(scores.dtype)
+    return g_lat, g_sc
 
-    def gather(t):
-        dev = t.device
-        if host_staged:
-            t = t.cpu()
-        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        pad[: t.shape[0]] = t
-        out = torch.empty((world * m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
-        return torch.cat([out[r * m: r * m + counts[r]] for r in range(world)], dim=0).to(dev)
 
-    return gather(latents), (None if scores is None else gather(scores))
+def merge_all_res(dst: Dict, part: Dict) -> Dict:
+    """Deep-merge one rank's all_res fragment ({uid: {target: {genre: record}}}, inference.py:421-452) into `dst`."""
+    for uid, targets in part.items():
+        for tgt, genres in targets.items():
+            dst.setdefault(uid, {}).setdefault(tgt, {}).update(genres)
+    return dst
 
 
 def save_batch_results(all_res: Dict, batch_uids, batch_genres, batch_history, batch_target_image_iid, batch_labels,
@@ -93,30 +107,45 @@ def generate_images(lavit, image_tokens: List[torch.Tensor], labels, uids, genre
                     height: int = 512, original_size=None, crops_coords_top_left=None, num_inference_steps: int = 25,
                     guidance_scale_for_dm: float = 7.0, generator: Optional[torch.Generator] = None,
                     rank: int = 0, world_size: int = 1, seed: int = 123, scorer=None, text_features=None,
-                    history_features=None):
+                    history_features=None, return_latents: bool = False):
     """inference.py:345-411 with optional rank sharding.  `lavit` is a PigeonPixelDecoder (or any object with the
     reference's generate_image signature).  Each outer batch of `batch_size*num_return_sequences` token sequences is
-    split over ranks; every rank writes the JPEGs of its own samples and returns its part of `all_res`
-    (rank 0 of a single-GPU run writes `all_res_dm_scale{g}.npy` exactly as the reference does).
+    split over ranks; every rank writes the JPEGs of its own samples.  After each outer batch the ranks exchange
+    (a) ONE all-gather of the final latents and per-image scores (RCCL over xGMI on the GPU, gloo in
+    the CPU tests) and (b) their `all_res` fragments, so every rank returns the full `all_res` of the 1-GPU run and
+    rank 0 writes `all_res_dm_scale{g}.npy` after every batch exactly as the reference does (inference.py:408).
 
     With a `scorer` (pigeon_amd.clip_vision.CLIPScorer.score, or any callable(images, text_features [n, D] | None,
     history_features [n, K, D] | None) -> [n, 2]) every rank scores its own images right after generating them
-    (cal_scores.py:144-203 fused into the run instead of re-reading the JPEGs); the per-image (tgt_score, hist_score)
-    rows are all-gathered once per outer batch and rank 0 writes `select_scores_dm_scale{g}.npy`
-    in cal_scores.py's layout.  `text_features` [n_tasks, D] / `history_features` [n_tasks, K, D] are per task.
-    Returns all_res, or (all_res, select_scores) when a scorer is given."""
+    (cal_scores.py:144-203 fused into the run instead of re-reading the JPEGs); rank 0 writes
+    `select_scores_dm_scale{g}.npy` in cal_scores.py's layout.  `text_features` [n_tasks, D] / `history_features`
+    [n_tasks, K, D] are per task.
+
+    Latents are collected when `lavit` can hand them over (PigeonPixelDecoder: `output_type="latent"` +
+    `decode_latents`); `return_latents=True` requires that and appends the gathered fp32 latents
+    [n_images, 4, h/8, w/8] (host memory, global image order, identical on every rank) to the return value.
+    Returns all_res, (all_res, select_scores) with a scorer, each followed by the latents when asked for."""
     total_token_num = len(image_tokens)
     step_num = batch_size * num_return_sequences
     total_steps = math.ceil(total_token_num / step_num)
     total_task_num = len(uids)
     all_res: Dict = {}
     gathered_scores: List[torch.Tensor] = []
+    gathered_latents: List[torch.Tensor] = []
     per_image = num_return_sequences * num_return_images
     token_start = 0
     device = lavit.device
     lat_c = lavit.unet.config.in_channels
+    lat_hw = (height // 8, width // 8)
+    has_latents = hasattr(lavit, "decode_latents")
+    if return_latents and not has_latents:
+        raise ValueError("return_latents needs a pipeline with output_type='latent' and decode_latents")
+    # the lowres decoder draws its noise on the HOST (lavit_for_pigeon.py:858-860): keep that stream when sharding
+    lowres = getattr(lavit, "pixel_decoding", "highres") == "lowres"
+    noise_device = torch.device("cpu") if lowres else device
     if world_size > 1 and generator is None:
-        generator = torch.Generator(device=device).manual_seed(seed)   # inference.py:317, identical on every rank
+        generator = torch.Generator(device=noise_device).manual_seed(seed)   # inference.py:317, identical on every rank
+    distributed = world_size > 1
     for step in range(total_steps):
         token_end = min(total_token_num, token_start + step_num)
         start = step * batch_size
@@ -126,10 +155,12 @@ def generate_images(lavit, image_tokens: List[torch.Tensor], labels, uids, genre
         lo, hi = shard_range(n_tasks, rank, world_size)
         tok_lo, tok_hi = token_start + lo * num_return_sequences, token_start + hi * num_return_sequences
         latents = None
-        if world_size > 1:
+        if distributed:
             n_img = (token_end - token_start) * num_return_images
-            noise = global_noise((n_img, lat_c, height // 8, width // 8), seed, device, generator)
-            latents = noise[lo * num_return_sequences * num_return_images: hi * num_return_sequences * num_return_images]
+            noise = global_noise((n_img, lat_c) + lat_hw, seed, noise_device, generator)
+            latents = noise[lo * per_image: hi * per_image]
+        batch_res: Dict = {}
+        final = torch.empty((0, lat_c) + lat_hw, dtype=torch.float32, device=device)
         if hi > lo:
             batch_tokens = [image_tokens[i].to(device) for i in range(tok_lo, tok_hi)]
             kwargs = dict(image_tokens=batch_tokens, num_return_images=num_return_images, width=width, height=height,
@@ -138,43 +169,62 @@ def generate_images(lavit, image_tokens: List[torch.Tensor], labels, uids, genre
                           generator=generator)
             if latents is not None:
                 kwargs["latents"] = latents
-            batch_images, _, _ = lavit.generate_image(**kwargs)
+            if has_latents:
+                final = lavit.generate_image(output_type="latent", **kwargs)[0].to(torch.float32)
+                batch_images = lavit.decode_latents(final, "pil")
+            else:
+                batch_images, _, _ = lavit.generate_image(**kwargs)
             if save_folder is not None:
                 image_save_folder = os.path.join(save_folder, f"dm_scale{guidance_scale_for_dm}")
                 os.makedirs(image_save_folder, exist_ok=True)
-                all_res = save_batch_results(all_res, uids[start + lo:start + hi], genres[start + lo:start + hi],
-                                             history[start + lo:start + hi], target_image_iid[start + lo:start + hi],
-                                             labels[start + lo:start + hi], batch_tokens, batch_images,
-                                             num_return_sequences, num_return_images, image_save_folder, eval_name,
-                                             img_folder_path, all_image_paths)
-                suffix = "" if world_size == 1 else f".rank{rank}"
-                np.save(os.path.join(save_folder, f"all_res_dm_scale{guidance_scale_for_dm}{suffix}.npy"),
-                        np.array(all_res))
+                save_batch_results(batch_res, uids[start + lo:start + hi], genres[start + lo:start + hi],
+                                   history[start + lo:start + hi], target_image_iid[start + lo:start + hi],
+                                   labels[start + lo:start + hi], batch_tokens, batch_images, num_return_sequences,
+                                   num_return_images, image_save_folder, eval_name, img_folder_path, all_image_paths)
+        sc = None
         if scorer is not None:
             if hi > lo:
                 tf = None if text_features is None else \
                     torch.as_tensor(text_features[start + lo:start + hi]).repeat_interleave(per_image, dim=0)
                 hf = None if history_features is None else \
                     torch.as_tensor(history_features[start + lo:start + hi]).repeat_interleave(per_image, dim=0)
-                sc = torch.as_tensor(scorer(batch_images, tf, hf), dtype=torch.float32)
+                sc = torch.as_tensor(scorer(batch_images, tf, hf), dtype=torch.float32).to(device)
             else:
-                sc = torch.empty(0, 2, dtype=torch.float32)
-            if world_size > 1:
-                counts = []
-                for r in range(world_size):
-                    a, b = shard_range(n_tasks, r, world_size)
-                    counts.append((b - a) * per_image)
-                dev_sc = sc.to(device) if dist.get_backend() != "gloo" else sc.cpu()
-                _, sc = all_gather_results(dev_sc.new_zeros((dev_sc.shape[0], 1)), dev_sc, counts)
+                sc = torch.empty(0, 2, dtype=torch.float32, device=device)
+        if distributed:
+            counts = []
+            for r in range(world_size):
+                a, b = shard_range(n_tasks, r, world_size)
+                counts.append((b - a) * per_image)
+            if has_latents or sc is not None:
+                # without latents (a foreign pipeline) a one-column dummy keeps the row layout
+                carry = final if has_latents else torch.zeros((counts[rank], 1), dtype=torch.float32, device=device)
+                final, sc = all_gather_results(carry, sc, counts)
+            if save_folder is not None:
+                parts = [None] * world_size
+                dist.all_gather_object(parts, batch_res)
+                for part in parts:              # rank order = task order (contiguous shards)
+                    merge_all_res(all_res, part)
+        else:
+            merge_all_res(all_res, batch_res)
+        if save_folder is not None and rank == 0:
+            np.save(os.path.join(save_folder, f"all_res_dm_scale{guidance_scale_for_dm}.npy"), np.array(all_res))
+        if sc is not None:
             gathered_scores.append(sc.cpu())
+        if return_latents:
+            gathered_latents.append(final.cpu())
         token_start += batch_size * num_return_sequences
-    if scorer is None:
-        return all_res
-    scores = torch.cat(gathered_scores, dim=0) if gathered_scores else torch.empty(0, 2)
-    select = select_scores_from_lists(uids, target_image_iid, genres, scores, num_return_sequences, num_return_images)
-    if save_folder is not None and rank == 0:
-        np.save(os.path.join(save_folder, f"select_scores_dm_scale{guidance_scale_for_dm}.npy"), np.array(select))
-    return all_res, select
+    out = [all_res]
+    if scorer is not None:
+        scores = torch.cat(gathered_scores, dim=0) if gathered_scores else torch.empty(0, 2)
+        select = select_scores_from_lists(uids, target_image_iid, genres, scores, num_return_sequences, num_return_images)
+        if save_folder is not None and rank == 0:
+            np.save(os.path.join(save_folder, f"select_scores_dm_scale{guidance_scale_for_dm}.npy"), np.array(select))
+        out.append(select)
+    if return_latents:
+        out.append(torch.cat(gathered_latents, dim=0) if gathered_latents
+                   else torch.empty((0, lat_c) + lat_hw, dtype=torch.float32))
+    return out[0] if len(out) == 1 else tuple(out)
 
 
 def select_scores_from_lists(uids, target_image_iid, genres, scores: torch.Tensor, num_return_sequences: int,

@@ -97,9 +97,10 @@ class BasicTransformerBlock(nn.Module):
     def _pending_biases(self, cb_in):
         """Running fp32 [C] totals of the biases owed by the bias-free accumulating GEMMs: what is pending after attn1,
         after attn2 and after the feed-forward, on top of what the previous block left (`cb_in`).  Cached per parameter
-        storage and incoming vector (inference: frozen weights, the same chain of blocks every call)."""
+        storage, VERSION and incoming vector (inference: frozen weights, the same chain of blocks every call; an
+        in-place update - load_state_dict, a LoRA merge - bumps `_version` and rebuilds the totals)."""
         bs = (self.attn1.to_out[0].bias, self.attn2.to_out[0].bias, self.ff.net[2].bias)
-        key = tuple(None if t is None else (t.data_ptr(), t.dtype) for t in bs + (cb_in,))
+        key = tuple(None if t is None else (t.data_ptr(), t.dtype, t._version) for t in bs + (cb_in,))
         if getattr(self, "_cb_key", None) != key:
             tot, out = cb_in, []
             for t in bs:

@@ -168,9 +168,17 @@ def test_ddim_thresholding_branch(stack):
     x0 = (torch.randn(2, 4, 8, 8, generator=g) * 2).to(torch.bfloat16)
     lat = torch.randn(2, 4, 8, 8, generator=g)
     out = s.step(x0.to(DEV), s._host_timesteps[0], lat.to(DEV))
-    thr = s._threshold_sample(x0.float())
+    thr = pipeline_ref.threshold_sample_ref(x0.float(), 0.9, 1.5)       # the oracle's own restatement (explicit sort)
     assert out.pred_original_sample.abs().max().item() <= 1.0 + 1e-6
-    assert torch.allclose(out.pred_original_sample.cpu().float(), thr, atol=1e-2)
+    assert torch.allclose(out.pred_original_sample.cpu().float(), thr, atol=2e-6, rtol=0)
+    # prev_sample from the thresholded x0 (prediction_type "sample": eps re-derived from x0), fp32 closed form
+    t, n = int(s._host_timesteps[0]), 5
+    r = pipeline_ref.DDIMRef(**cfg)
+    r.set_timesteps(n)
+    a_t, a_p = r.alphas_cumprod[t].double(), r.alphas_cumprod[t - 1000 // n].double()
+    eps = (lat.double() - a_t.sqrt() * thr.double()) / (1 - a_t).sqrt()
+    want_prev = a_p.sqrt() * thr.double() + (1 - a_p).sqrt() * eps
+    assert torch.allclose(out.prev_sample.cpu().double(), want_prev, atol=2e-5, rtol=0)
 
 
 def test_vae_decode_matches_oracle(stack):

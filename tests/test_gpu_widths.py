@@ -243,3 +243,23 @@ def test_generate_image_fp16_per_step_latents_fixed_bar(stack16):
     d = np.abs(images.cpu().numpy().astype(int) - ref["images"].astype(int))
     print(f"fp16 images: mean |d| {d.mean():.3f} / 255, max {d.max()}")
     assert d.mean() < 0.5 and d.max() <= 4
+
+
+def test_in_place_weight_update_reaches_the_pending_bias_chain():
+    # forward, load_state_dict (copies into the same storage), forward -> the second output follows the new
+    # biases (the cached fp32 totals are keyed on the parameters' version)
+    from pigeon_amd.unet import BasicTransformerBlock
+    dt = torch.bfloat16
+    blk, sd = _load(BasicTransformerBlock(640, 10, 64, 2048), 31, dt)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 256, 640, generator=g).to(dt)
+    ctx = (torch.randn(2, 256, 2048, generator=g) * 0.6).to(dt)
+    first = blk(x.to(DEV), ctx.to(DEV))
+    new = {k: v.clone() for k, v in blk.state_dict().items()}
+    for k in ("attn1.to_out.0.bias", "attn2.to_out.0.bias", "ff.net.2.bias"):
+        new[k] = (new[k].float() + 0.5).to(dt)
+    blk.load_state_dict(new)
+    second = blk(x.to(DEV), ctx.to(DEV))
+    want = models_ref.transformer_block(F32, SD({k: v.float().cpu() for k, v in new.items()}), x.float(), ctx.float(), 10)
+    assert _rel(second, first) > 0.3
+    _check(second, want, BLOCK_BAR[dt], "BasicTransformerBlock after load_state_dict")

@@ -42,3 +42,28 @@ def test_self_attention_on_cpu_uses_separate_projections_and_keeps_the_state_dic
         q, k, v = ap.HipAttnProcessor._self_qkv(attn, x)
     assert torch.equal(q, attn.to_q(x)) and torch.equal(k, attn.to_k(x)) and torch.equal(v, attn.to_v(x))
     assert not hasattr(attn, "_qkv_fused") and set(attn.state_dict()) == keys
+
+
+def test_pending_bias_totals_follow_in_place_weight_updates():
+    # the fp32 bias totals a BasicTransformerBlock carries into its LayerNorms are cached; load_state_dict
+    # copies INTO the existing parameters (same data_ptr), so the cache key must see the version bump
+    from pigeon_amd.unet import BasicTransformerBlock
+    torch.manual_seed(3)
+    blk = BasicTransformerBlock(32, 2, 16, 24).eval().requires_grad_(False)
+    b1, b2, b3 = blk.attn1.to_out[0].bias, blk.attn2.to_out[0].bias, blk.ff.net[2].bias
+    c1, c12, c123 = blk._pending_biases(None)
+    assert torch.equal(c1, b1.float()) and torch.equal(c12, b1.float() + b2.float())
+    assert torch.equal(c123, b1.float() + b2.float() + b3.float())
+    assert blk._pending_biases(None)[2] is c123                        # cached while nothing changed
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    sd["attn2.to_out.0.bias"] += 1.0
+    ptr = b2.data_ptr()
+    blk.load_state_dict(sd)
+    assert blk.attn2.to_out[0].bias.data_ptr() == ptr                  # in place: storage unchanged
+    n1, n12, n123 = blk._pending_biases(None)
+    assert torch.equal(n1, c1) and torch.allclose(n12, c12 + 1.0) and torch.allclose(n123, c123 + 1.0)
+    # an incoming pending vector (what the previous block of the chain owes) is part of the totals and of the key
+    cb = torch.full((32,), 0.25)
+    assert torch.allclose(blk._pending_biases(cb)[0], n1 + 0.25)
+    cb += 1.0
+    assert torch.allclose(blk._pending_biases(cb)[0], n1 + 1.25)

@@ -186,3 +186,18 @@ def test_product_has_no_cpu_fallback():
         ops.attention(torch.zeros(1, 4, 64), torch.zeros(1, 4, 64), torch.zeros(1, 4, 64), 1)
     with pytest.raises(RuntimeError):
         ops.cfg_ddim_step(torch.zeros(2, 4), torch.zeros(1, 4), 7.0, 1, 1, 1, 1)
+
+
+def test_threshold_sample_known_answers():
+    # dynamic thresholding by hand: |x| = 0..9 -> 0.9-quantile = 8.1 (linear interpolation), clamped to max 4 -> s = 4;
+    # a sample whose quantile is below 1 keeps s = 1 (plain clip to [-1, 1])
+    from oracle.pipeline_ref import threshold_sample_ref
+    x = torch.tensor([[0., -1, 2, -3, 4, -5, 6, -7, 8, -9], [0.05 * i for i in range(10)]]).reshape(2, 10, 1, 1)
+    y = threshold_sample_ref(x, 0.9, 4.0).reshape(2, 10)
+    assert torch.allclose(y[0], torch.tensor([0., -0.25, 0.5, -0.75, 1, -1, 1, -1, 1, -1]))
+    assert torch.allclose(y[1], x.reshape(2, 10)[1])
+    y = threshold_sample_ref(x, 0.9, 100.0).reshape(2, 10)
+    assert torch.allclose(y[0], (x.reshape(2, 10)[0] / 8.1).clamp(-1, 1))
+    # and the torch.quantile form diffusers uses gives the same numbers
+    q = torch.quantile(x.reshape(2, 10).abs(), 0.9, dim=1)
+    assert torch.allclose(q, torch.tensor([8.1, 0.405]))

@@ -53,6 +53,26 @@ class _FakeLavit:
         return images, None, None
 
 
+class _FakeLatentLavit(_FakeLavit):
+    """The PigeonPixelDecoder surface the runner uses to collect latents: generate_image(output_type="latent") returns
+    the final latents (here: noise * 0.5 + token-sum / 1e6, so they depend on both inputs), decode_latents turns them
+    into images."""
+
+    def generate_image(self, image_tokens=None, num_return_images=1, width=512, height=512, original_size=None,
+                       crops_coords_top_left=None, num_inference_steps=25, guidance_scale_for_diffusion=7.0,
+                       generator=None, latents=None, output_type="pil"):
+        assert output_type == "latent"
+        n = len(image_tokens) * num_return_images
+        if latents is None:
+            latents = torch.randn((n, 4, height // 8, width // 8), generator=generator)
+        self.calls.append((len(image_tokens), num_return_images))
+        shift = torch.tensor([float(image_tokens[i // num_return_images].sum()) / 1e6 for i in range(n)])
+        return latents * 0.5 + shift[:, None, None, None], None, None
+
+    def decode_latents(self, latents, output_type="pil"):
+        return [_FakeImage((0, round(float(x.double().sum()), 6))) for x in latents]
+
+
 def _fake_scorer(images, text_features, history_features):
     """(token-sum of the image mod 97, its task's text feature): depends on which image and which task row it got."""
     return torch.tensor([[img.value[0] % 97, float(text_features[i, 0])] for i, img in enumerate(images)])
@@ -143,6 +163,17 @@ def _rank_main(rank, world, port, tmp, n_tasks, nrs, nri, bs):
                                         world_size=world, seed=123, scorer=_fake_scorer,
                                         text_features=torch.arange(n_tasks, dtype=torch.float32)[:, None])
         torch.save(sel, os.path.join(tmp, f"sel_rank{rank}.pt"))
+        # (1c) a pipeline that hands over latents: final latents and scores travel in ONE all-gather per outer batch
+        #      and every rank ends up with the latents of the whole run, in global image order
+        res, sel2, lat = runner.generate_images(_FakeLatentLavit(), tokens, labels, uids, genres, targets, history,
+                                                num_return_sequences=nrs, batch_size=bs,
+                                                save_folder=os.path.join(tmp, "w2l"), eval_name="e",
+                                                num_return_images=nri, width=64, height=64, rank=rank,
+                                                world_size=world, seed=123, scorer=lambda im, tf, hf: torch.tensor(
+                                                    [[x.value[1], float(tf[i, 0])] for i, x in enumerate(im)]),
+                                                text_features=torch.arange(n_tasks, dtype=torch.float32)[:, None],
+                                                return_latents=True)
+        torch.save((res, sel2, lat), os.path.join(tmp, f"lat_rank{rank}.pt"))
         # (2) padded all-gather with uneven counts: rank r contributes r+2 rows
         counts = [r + 2 for r in range(world)]
         lat = torch.full((counts[rank], 4, 2, 2), float(rank + 1))
@@ -185,5 +216,49 @@ def test_world2_gloo_sharded_run_equals_single_rank_run(tmp_path):
     assert rec["hist_score"] == [3.0] * nri and rec["tgt_score"] == [float(int(tokens[3 * nrs + 1].sum()) % 97)] * nri
     on_disk = np.load(tmp_path / "w2s" / "select_scores_dm_scale7.0.npy", allow_pickle=True).item()
     assert on_disk == sel1
-    assert os.path.exists(tmp_path / "w2" / "all_res_dm_scale7.0.rank0.npy")
-    assert os.path.exists(tmp_path / "w2" / "all_res_dm_scale7.0.rank1.npy")
+    # all_res: ONE reference-format file, written by rank 0 from the merged fragments, equal to the 1-rank file
+    assert not os.path.exists(tmp_path / "w2" / "all_res_dm_scale7.0.rank0.npy")
+    res1 = np.load(tmp_path / "w1" / "all_res_dm_scale7.0.npy", allow_pickle=True).item()
+    res2 = np.load(tmp_path / "w2" / "all_res_dm_scale7.0.npy", allow_pickle=True).item()
+    assert list(res1) == list(res2) == uids          # task order survives the merge
+    for i, uid in enumerate(uids):
+        a, b = res1[uid][targets[i]][genres[i]], res2[uid][targets[i]][genres[i]]
+        assert torch.equal(a["history"], b["history"]) and torch.equal(a["labels"], b["labels"])
+        assert sorted(a["seqs"]) == sorted(b["seqs"]) == list(range(nrs))
+        for sq in range(nrs):
+            assert torch.equal(a["seqs"][sq]["tokens"], b["seqs"][sq]["tokens"])
+            assert [x.replace("/w1/", "/w2/") for x in a["seqs"][sq]["images"]] == b["seqs"][sq]["images"]
+    # latents: the 2-rank run returns, on BOTH ranks, the latents of the 1-rank run (same seed, global noise sliced)
+    res_1, sel_1, lat_1 = runner.generate_images(
+        _FakeLatentLavit(), tokens, labels, uids, genres, targets, history, num_return_sequences=nrs, batch_size=bs,
+        save_folder=str(tmp_path / "w1l"), eval_name="e", num_return_images=nri, width=64, height=64,
+        generator=torch.Generator().manual_seed(123), scorer=lambda im, tf, hf: torch.tensor(
+            [[x.value[1], float(tf[i, 0])] for i, x in enumerate(im)]),
+        text_features=torch.arange(n_tasks, dtype=torch.float32)[:, None], return_latents=True)
+    assert lat_1.shape == (n_tasks * nrs * nri, 4, 8, 8) and lat_1.dtype == torch.float32
+    for r in range(2):
+        res_r, sel_r, lat_r = torch.load(tmp_path / f"lat_rank{r}.pt")
+        assert torch.equal(lat_r, lat_1) and sel_r == sel_1 and list(res_r) == uids
+    assert _read_tree(str(tmp_path / "w1l")) == _read_tree(str(tmp_path / "w2l"))
+    with pytest.raises(ValueError):
+        runner.generate_images(_FakeLavit(), tokens, labels, uids, genres, targets, history, return_latents=True)
+
+
+def test_lowres_sharded_noise_comes_from_the_host_stream():
+    # lavit_for_pigeon.py:858-860: the lowres decoder draws noise from a CPU generator; the sharded runner must draw
+    # the global noise from the same stream (here world_size 2 simulated rank by rank without a process group)
+    calls = []
+
+    class Lowres(_FakeLavit):
+        pixel_decoding = "lowres"
+        device = torch.device("meta")      # any non-CPU device: the generator must still be a CPU one
+
+        def generate_image(self, latents=None, generator=None, **kw):
+            calls.append((latents.device.type, generator.device.type))
+            raise StopIteration
+
+    tokens, labels, uids, genres, targets, history = _inputs(2, 1)
+    with pytest.raises(StopIteration):
+        runner.generate_images(Lowres(), tokens, labels, uids, genres, targets, history, batch_size=2, width=64,
+                               height=64, rank=0, world_size=2, seed=5)
+    assert calls == [("cpu", "cpu")]

@@ -81,18 +81,22 @@ def test_preprocess_shapes_and_normalisation():
 
 
 def test_select_scores_layout_matches_cal_scores():
-    # cal_scores.py:184-204: select_scores[uid][tgt][genre][seq] = {"tgt_score": [per image], "hist_score": [...]}
-    from pigeon_amd.clip_vision import build_select_scores
-    all_res = {7: {100: {0: {}}, 101: {1: {}}}, 9: {100: {0: {}}}}          # 3 tasks in iteration order
+    # cal_scores.py:184-204: select_scores[uid][tgt][genre][seq] = {"tgt_score": [per image], "hist_score": [...]};
+    # score rows are in TASK order (inference.py:447-448), and a user's tasks need not be contiguous in the task list
+    from pigeon_amd.runner import select_scores_from_lists
+    uids, targets, genres = [7, 9, 7, 9], [100, 100, 101, 102], [0, 0, 1, 2]     # interleaved users
     nrs, nri = 2, 3
-    scores = torch.arange(3 * nrs * nri * 2, dtype=torch.float32).view(-1, 2)
-    out = build_select_scores(all_res, scores, nrs, nri)
-    assert list(out) == [7, 9] and list(out[7]) == [100, 101]
-    rec = out[7][101][1][1]                    # task 1, sequence 1 -> images (1*2+1)*3 + j
-    assert rec["tgt_score"] == [float(scores[9 + j, 0]) for j in range(3)]
-    assert rec["hist_score"] == [float(scores[9 + j, 1]) for j in range(3)]
+    scores = torch.arange(4 * nrs * nri * 2, dtype=torch.float32).view(-1, 2)
+    out = select_scores_from_lists(uids, targets, genres, scores, nrs, nri)
+    assert sorted(out) == [7, 9] and sorted(out[7]) == [100, 101] and sorted(out[9]) == [100, 102]
+    for i, (u, t, g) in enumerate(zip(uids, targets, genres)):
+        for seq in range(nrs):
+            rec = out[u][t][g][seq]                # task i, sequence seq -> images (i*nrs+seq)*nri + j
+            base = (i * nrs + seq) * nri
+            assert rec["tgt_score"] == [float(scores[base + j, 0]) for j in range(nri)]
+            assert rec["hist_score"] == [float(scores[base + j, 1]) for j in range(nri)]
     with pytest.raises(ValueError):
-        build_select_scores(all_res, scores[:-1], nrs, nri)
+        select_scores_from_lists(uids, targets, genres, scores[:-1], nrs, nri)
     np.save("/tmp/_sel.npy", np.array(out))    # same container the reference writes (np.save of a dict)
     assert np.load("/tmp/_sel.npy", allow_pickle=True).item()[9][100][0][0]["tgt_score"] == out[9][100][0][0]["tgt_score"]
 
