@@ -188,17 +188,17 @@ class HipAttnProcessor:
         return out
 
 
-class TorchSdpaAttnProcessor:
-    """torch.nn.functional.scaled_dot_product_attention on the GPU, for head sizes the HIP kernel does not cover
-    yet (e.g. the VAE's single 512-wide head; the reference leaves that one on diffusers' default processor too:
-    only `self.unet` is switched at lavit_for_pigeon.py:202).  On the GPU in bf16 / fp16 the softmax runs in the HIP
-    row kernel between two hipBLASLt GEMMs (ops.wide_head_attention: 1.1 ms instead of 3.0 ms per 1024^2 image);
-    masks, fp32 (the upcast path) and CPU tensors take torch's fused kernel."""
-
-    def __init__(self, use_hip_softmax: bool = True):
-        self.use_hip_softmax = use_hip_softmax
+class WideHeadAttnProcessor:
+    """Processor for head sizes beyond the fused kernel's 256: the VAE decoder's single 512-wide head (the reference
+    leaves that one on diffusers' default processor: only `self.unet` is switched at lavit_for_pigeon.py:202).  Per
+    (sample, head): 16-bit GEMM with fp32 scores (hipBLASLt) -> pgn_softmax_rows -> 16-bit GEMM
+    (ops.wide_head_attention: 1.1 ms instead of 3.0 ms per 1024^2 image for torch's fused SDPA), the fused kernel's
+    rounding points.  bf16 / fp16 device tensors without a mask only - what the path produces (after `upcast_vae` the
+    mid block is back in fp16, lavit_for_pigeon.py:808-813); anything else raises instead of falling back to torch."""
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, *a, **kw):
+        if attention_mask is not None:
+            raise NotImplementedError("WideHeadAttnProcessor: attention masks are not on the Pigeon path")
         residual = hidden_states
         input_ndim = hidden_states.ndim
         if input_ndim == 4:
@@ -212,17 +212,9 @@ class TorchSdpaAttnProcessor:
         q = attn.to_q(hidden_states).view(B, Nq, H, C // H).transpose(1, 2)
         k = attn.to_k(context).view(B, -1, H, C // H).transpose(1, 2)
         v = attn.to_v(context).view(B, -1, H, C // H).transpose(1, 2)
-        mask = None
-        if attention_mask is not None:
-            mask = attention_mask.to(q.dtype)
-            mask = mask[:, None, :, :] if mask.dim() == 3 else mask[:, None, None, :]
-        if (self.use_hip_softmax and mask is None and q.is_cuda and q.dtype in (torch.bfloat16, torch.float16)
-                and (C // H) % 8 == 0):
-            # 16-bit GEMM (fp32 scores) -> pgn_softmax_rows -> 16-bit GEMM, per (sample, head)
-            o = torch.stack([torch.stack([ops.wide_head_attention(q[i, j], k[i, j], v[i, j], attn.scale)
-                                          for j in range(H)]) for i in range(B)])
-        else:
-            o = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=mask, scale=attn.scale)
+        # ops.wide_head_attention raises on CPU / fp32 tensors
+        o = torch.stack([torch.stack([ops.wide_head_attention(q[i, j], k[i, j], v[i, j], attn.scale)
+                                      for j in range(H)]) for i in range(B)])
         hidden_states = attn.to_out[1](attn.to_out[0](o.transpose(1, 2).reshape(B, Nq, C)))
         if input_ndim == 4:
             hidden_states = hidden_states.transpose(-1, -2).reshape(b, c, h, w)

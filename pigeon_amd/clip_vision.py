@@ -33,16 +33,9 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
-def _on_hip(x: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)
-
-
 def _layer_norm(x, residual, ln: nn.LayerNorm):
-    """(x + residual, LayerNorm(x + residual)) — one HIP launch on the GPU."""
-    if _on_hip(x):
-        return ops.add_layer_norm(x, residual, ln.weight, ln.bias, ln.eps)
-    s = x if residual is None else x + residual
-    return s, F.layer_norm(s.float(), ln.normalized_shape, ln.weight.float(), ln.bias.float(), ln.eps).to(s.dtype)
+    """(x + residual, LayerNorm(x + residual)): one pgn_add_layernorm launch; no torch evaluation (CPU tensors raise)."""
+    return ops.add_layer_norm(x, residual, ln.weight, ln.bias, ln.eps)
 
 
 class _MHA(nn.Module):
@@ -61,13 +54,7 @@ class _MHA(nn.Module):
         qkv = F.linear(x, self.in_proj_weight, self.in_proj_bias)          # [B, N, 3C] = [q | k | v]
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         D = C // self.heads
-        if _on_hip(x):
-            o = ops.attention(q, k, v, self.heads, D ** -0.5)
-        else:
-            split = lambda t: t.reshape(B, N, self.heads, D).transpose(1, 2)
-            o = F.scaled_dot_product_attention(split(q), split(k), split(v), scale=D ** -0.5)
-            o = o.transpose(1, 2).reshape(B, N, C)
-        return self.out_proj(o)
+        return self.out_proj(ops.attention(q, k, v, self.heads, D ** -0.5))      # pgn_attention_fwd (head dim 80)
 
 
 class _MLP(nn.Module):

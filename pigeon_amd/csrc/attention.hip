@@ -365,12 +365,19 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
     }
 }
 
-int g_attn_variant = 0;  // tuning hook (scripts/bench_kernels.py): 0 = heuristic, 1 = force 8 waves, 2 = force 4 waves
+#ifdef PGN_TUNING_HOOKS
+int g_attn_variant = 0;  // 0 = shipped geometry, 1 = force 8 waves (256 query rows per workgroup)
+#else
+constexpr int g_attn_variant = 0;
+#endif
 
 }  // namespace
 
-// not part of the public ABI (absent from pigeon_hip.h): geometry override for A/B benchmarking in one process
+#ifdef PGN_TUNING_HOOKS
+// Only in the measurement build (make tuning -> libpigeon_hip_tuning.so, loaded by scripts/bench_kernels.py): geometry
+// override for A/B runs in one process.  The shipped library has no such export and no mutable global state.
 extern "C" void pgn_attention_tuning(int variant) { g_attn_variant = variant; }
+#endif
 
 extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H,
                                  int Nq, int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb,
@@ -393,10 +400,9 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     // SIMD come from DIFFERENT workgroups, so one workgroup's barrier / prologue / epilogue hides behind the others'
     // main loops.  Measured on MI355X at every
     // SDXL shape (scripts/bench_kernels.py): 4 waves beat the 8-wave 256-row geometry by 4 % (self, N 4096) to
-    // 30 % (cross, Nk 256); the 8-wave form stays reachable through pgn_attention_tuning for A/B runs.
+    // 30 % (cross, Nk 256); the 8-wave form is compiled into the measurement build only (PGN_TUNING_HOOKS).
     int nw = 4;
     if (g_attn_variant == 1 && D == 64) nw = 8;
-    if (g_attn_variant == 2) nw = 4;
     const int bm = nw * 32;
     const long long nqt = (Nq + bm - 1) / bm;
     const long long blocks = (long long)B * H * nqt;
@@ -411,11 +417,17 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     a.c = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), block(nw * 64);
+#ifdef PGN_TUNING_HOOKS
+#define PGN_ATT_LAUNCH_8W(DT, BIAS) \
+    if (nw == 8) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 8, 2, 64, false>), grid, block, 0, s, a); else
+#else
+#define PGN_ATT_LAUNCH_8W(DT, BIAS)
+#endif
 #define PGN_ATT_LAUNCH(DT, BIAS)                                                                                  \
     do {                                                                                                          \
         if (D == 64) {                                                                                            \
-            if (nw == 8) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 8, 2, 64, false>), grid, block, 0, s, a); \
-            else hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 3, 64, false>), grid, block, 0, s, a);        \
+            PGN_ATT_LAUNCH_8W(DT, BIAS)                                                                           \
+            hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 3, 64, false>), grid, block, 0, s, a);             \
         } else if (D < 64) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 3, 64, true>), grid, block, 0, s, a); \
         else if (D == 128) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 128, false>), grid, block, 0, s, a); \
         else if (D < 128) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 2, 128, true>), grid, block, 0, s, a); \
@@ -430,6 +442,7 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
         else PGN_ATT_LAUNCH(PGN_F16, false);
     }
 #undef PGN_ATT_LAUNCH
+#undef PGN_ATT_LAUNCH_8W
     PGN_LAUNCH_CHECK();
     return PGN_OK;
 }

@@ -324,8 +324,13 @@ extern "C" int pgn_geglu(const void* h, void* y, int dtype, int64_t M, int D, in
     return PGN_OK;
 }
 
-int g_ln_rows2_max_r = 2;   // measured: C = 640 95 -> 78 us, C = 320 216 -> 162 us at 131 k / 524 k rows; C = 1280 (3 vectors per lane) loses 7 %
-extern "C" void pgn_layernorm_tuning(int rows2_max_r) { g_ln_rows2_max_r = rows2_max_r; }
+#ifdef PGN_TUNING_HOOKS
+int g_ln_rows2_max_r = 2;
+extern "C" void pgn_layernorm_tuning(int rows2_max_r) { g_ln_rows2_max_r = rows2_max_r; }   // measurement build only
+#else
+constexpr int g_ln_rows2_max_r = 2;
+#endif
+// measured: C = 640 95 -> 78 us, C = 320 216 -> 162 us at 131 k / 524 k rows; C = 1280 (3 vectors per lane) loses 7 %
 
 extern "C" int pgn_add_layernorm(const void* x, const void* residual, void* sum_out, void* y, const void* gamma,
                                  const void* beta, int dtype, int affine_dtype, int64_t M, int C, float eps,

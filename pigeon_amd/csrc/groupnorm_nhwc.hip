@@ -249,8 +249,12 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArg
     }
 }
 
-// tuning hook (not part of the ABI): workgroups aimed at per launch, minimum rows per lane
-int g_nh_target_wgs = 768, g_nh_min_rows_per_lane = 24;   // swept on MI355X (scripts/gn_exp.py): fewer, longer workgroups
+// workgroups aimed at per launch, minimum rows per lane: swept on MI355X (scripts/gn_exp.py): fewer, longer workgroups
+#ifdef PGN_TUNING_HOOKS
+int g_nh_target_wgs = 768, g_nh_min_rows_per_lane = 24;
+#else
+constexpr int g_nh_target_wgs = 768, g_nh_min_rows_per_lane = 24;
+#endif
 
 // geometry shared by the workspace query and the launch
 static bool nh_geometry(int N, int C, int HW, int G, NhArgs* a) {
@@ -274,10 +278,13 @@ static bool nh_geometry(int N, int C, int HW, int G, NhArgs* a) {
 
 }  // namespace
 
+#ifdef PGN_TUNING_HOOKS
+// measurement build only (make tuning): geometry sweep hook of scripts/gn_exp.py; absent from the shipped library
 extern "C" void pgn_groupnorm_nhwc_tuning(int target_wgs, int min_rows_per_lane) {
     g_nh_target_wgs = target_wgs;
     g_nh_min_rows_per_lane = min_rows_per_lane;
 }
+#endif
 
 extern "C" size_t pgn_groupnorm_nhwc_workspace_bytes(int N, int C, int HW, int G) {
     NhArgs a;

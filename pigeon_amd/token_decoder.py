@@ -10,8 +10,9 @@ order; the reference's per-sample Python pad loop :315-317 and its `.tolist()` /
     padded key columns receive the same additive -10000 bias as the reference's mask, i.e. exactly zero weight;
   * on the GPU the 88-wide attention heads (self, masked cross, pool) run in the HIP MFMA kernel (pgn_attention_fwd,
     head dims up to 128) reading the fused qkv / key / value projections in place, and the fp32-statistics LayerNorms
-    in the HIP row kernel (pgn_add_layernorm) — no materialised [B, 16, 256, L] score tensors.  Called on CPU tensors
-    (host-logic tests against the reference's golden vectors) the same module evaluates with torch ops;
+    in the HIP row kernel (pgn_add_layernorm) — no materialised [B, 16, 256, L] score tensors.  There is no torch
+    evaluation of these two ops: CPU or fp32 tensors raise (the host logic is pinned on the GPU, in fp16, against the
+    reference's golden vectors: tests/test_gpu_models.py);
   * the attention pool evaluates only the one query row whose output is used (`x[0]`, :177).
 `forward(x, token_num)` keeps the reference signature (packed rows + counts).
 `VQDecoder` is the lowres twin (modeling_decoder.py:180-254, `tokenizer_decoder.bin`) used by
@@ -27,31 +28,17 @@ import torch.nn.functional as F
 from . import ops
 
 
-def _on_hip(x: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)
-
-
 def _attention(q, k, v, heads: int, scale: float, key_bias: Optional[torch.Tensor] = None):
-    """softmax(q k^T * scale + key_bias) v on [B, N, heads*D] tensors (last dim contiguous, any row stride)."""
-    if _on_hip(q):
-        return ops.attention(q, k, v, heads, scale, key_bias)
-    B, Nq, C = q.shape
-    D = C // heads
-    split = lambda t: t.reshape(B, -1, heads, D).transpose(1, 2)
-    mask = None if key_bias is None else key_bias[:, None, None, :].to(q.dtype)
-    o = F.scaled_dot_product_attention(split(q), split(k), split(v), attn_mask=mask, scale=scale)
-    return o.transpose(1, 2).reshape(B, Nq, C)
+    """softmax(q k^T * scale + key_bias) v on [B, N, heads*D] tensors (last dim contiguous, any row stride):
+    pgn_attention_fwd, nothing else (CPU tensors raise RuntimeError, fp32 NotImplementedError)."""
+    return ops.attention(q, k, v, heads, scale, key_bias)
 
 
 class _LayerNormFp32(nn.LayerNorm):
-    """fp32 statistics regardless of the activation dtype (modeling_decoder.py:11-17)."""
+    """fp32 statistics regardless of the activation dtype (modeling_decoder.py:11-17): pgn_add_layernorm."""
 
     def forward(self, x):
-        if _on_hip(x) and self.weight is not None and x.shape[-1] % 8 == 0:
-            return ops.add_layer_norm(x, None, self.weight, self.bias, self.eps)[1]
-        w = None if self.weight is None else self.weight.float()
-        b = None if self.bias is None else self.bias.float()
-        return F.layer_norm(x.float(), self.normalized_shape, w, b, self.eps).to(x.dtype)
+        return ops.add_layer_norm(x, None, self.weight, self.bias, self.eps)[1]
 
 
 class _Mlp(nn.Module):

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from .attention_processor import Attention, TorchSdpaAttnProcessor
+from .attention_processor import Attention, WideHeadAttnProcessor
 from .layers import GroupNormAct, ResnetBlock2D, Upsample2D, conv2d_bias
 
 
@@ -40,7 +40,7 @@ class _MidBlock(nn.Module):
         self.attentions = nn.ModuleList([
             Attention(ch, None, heads=ch // attention_head_dim, dim_head=attention_head_dim, bias=True,
                       norm_num_groups=groups, eps=1e-6, residual_connection=True,
-                      processor=TorchSdpaAttnProcessor())])
+                      processor=WideHeadAttnProcessor())])
 
     def forward(self, x):
         x = self.resnets[0](x)

@@ -6,7 +6,9 @@ import torch
 from oracle import ops_ref
 from pigeon_amd import ops, _lib
 var = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-_lib.load().pgn_attention_tuning(var)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _tuning_lib import use_tuning_lib
+use_tuning_lib().pgn_attention_tuning(var)
 bad = 0
 for B, H, Nq, Nk, has_bias in ((2, 10, 1024, 1024, False), (1, 4, 4096, 4096, False), (2, 20, 1024, 256, False), (2, 5, 988, 988, False),
                                (1, 2, 3952, 3952, False), (2, 4, 300, 77, True), (3, 2, 1, 1, False), (2, 3, 257, 65, False),

@@ -26,11 +26,17 @@ for name, H, Nq, Nk in shapes_cfg5 if os.environ.get("SHAPES") == "cfg5" else ((
     q = torch.randn(Bp, Nq, C, device=dev).bfloat16(); k = torch.randn(Bp, Nk, C, device=dev).bfloat16(); v = torch.randn(Bp, Nk, C, device=dev).bfloat16()
     fl = 4.0 * Bp * H * Nq * Nk * 64
     from pigeon_amd import _lib
-    for var, vn in ((1, "8w"), (2, "4w")):
-        _lib.load().pgn_attention_tuning(var)
+    variants = ((0, "4w"),)
+    if os.environ.get("TUNING"):       # measurement build (make -C pigeon_amd/csrc tuning): also the 8-wave geometry
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from _tuning_lib import use_tuning_lib
+        use_tuning_lib()
+        variants = ((1, "8w"), (0, "4w"))
+    for var, vn in variants:
+        if os.environ.get("TUNING"):
+            _lib.load().pgn_attention_tuning(var)
         t = timeit(lambda: ops.attention(q, k, v, H))
         res.append((f"attn_{name}_{vn}", t * 1e6, fl / t / 1e12, "TFLOP/s"))
-    _lib.load().pgn_attention_tuning(0)
     tq = q.view(Bp, Nq, H, 64).transpose(1, 2); tk = k.view(Bp, Nk, H, 64).transpose(1, 2); tv = v.view(Bp, Nk, H, 64).transpose(1, 2)
     if os.environ.get("SDPA"):
         t2 = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(tq, tk, tv), iters=5, warm=2)

@@ -10,8 +10,9 @@ def timeit(fn, iters=20, warm=3):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e-3
-from pigeon_amd import _lib
-lib = _lib.load()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _tuning_lib import use_tuning_lib
+lib = use_tuning_lib()
 for tw, mr in ((2048, 8), (768, 24), (1024, 32), (512, 24), (768, 32), (768, 16), (1024, 24)):
   lib.pgn_groupnorm_nhwc_tuning(tw, mr)
   tot = 0.0

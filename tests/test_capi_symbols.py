@@ -28,6 +28,15 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in pigeon_hip.h but not exported"
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    # no undeclared entry points (tuning hooks live in the separate measurement build, `make tuning`)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("pgn_")
+                       and ln.split()[-2] in ("T", "t")})
+    assert exported == _declared()
+
+
 def test_binding_table_matches_header():
     assert sorted(_lib.SIGNATURES) == _declared()
 

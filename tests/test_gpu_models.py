@@ -82,6 +82,51 @@ def test_token_decoder_gpu_matches_oracle(stack):
     _calibrated(pooled, want_pooled, want_pooled32, 0.03, "token decoder pooled")
 
 
+def _golden_rel(got, want):
+    got, want = torch.as_tensor(got).double(), torch.as_tensor(want).double()
+    return ((got - want).norm() / want.norm()).item()
+
+
+@pytest.mark.parametrize("dt,bar", [(torch.float16, 0.002), (torch.bfloat16, 0.016)], ids=["fp16", "bf16"])
+def test_product_token_decoders_match_the_reference_golden_vectors(golden_dir, dt, bar):
+    # tests/golden/*.npz hold outputs of the reference's OWN modeling_decoder.py (HighresVQDecoder / VQDecoder, fp32,
+    # scripts/gen_golden.py).  The product decoders run on the GPU through the HIP gather / attention / LayerNorm
+    # kernels in 16-bit and are compared with those fp32 vectors under a FIXED bar (measured relL2, weights rounded
+    # to the 16-bit type included: fp16 0.0009-0.0013, bf16 0.007-0.010): this is the one part of the path whose parity is pinned by the reference itself.
+    import os
+    from pigeon_amd import ops
+    from pigeon_amd.token_decoder import HighresVQDecoder, VQDecoder
+    codebook = weights.synth_codebook().to(DEV)
+    g = np.load(os.path.join(golden_dir, "token_decoder_depth2.npz"))
+    m = HighresVQDecoder(depth=2)
+    m.load_state_dict(weights.synth_like(m, seed=123))
+    m = m.to(DEV, dt).eval().requires_grad_(False)
+    tokens = [t.to(DEV) for t in torch.from_numpy(g["tokens"])]
+    out = ops.token_gather(tokens, codebook, out_dtype=dt)
+    assert out["token_nums"].tolist() == g["token_nums"].tolist()
+    rows = torch.from_numpy(g["prompt_rows"])
+    with torch.no_grad():
+        total = int(out["token_nums"].sum())
+        for what, (prompt, pooled) in (("padded", m.forward_padded(out["padded"], out["mask"])),
+                                       ("packed", m(out["packed"][:total], out["token_nums"]))):
+            e1 = _golden_rel(prompt[:, rows].float().cpu(), g["prompt_embeds_rows"])
+            e2 = _golden_rel(pooled.float().cpu(), g["pooled"])
+            print(f"HighresVQDecoder {what} {dt}: relL2 vs reference golden {e1:.5f} / pooled {e2:.5f}")
+            assert e1 < bar and e2 < bar, (what, e1, e2)
+    g = np.load(os.path.join(golden_dir, "vq_decoder_lowres_depth2.npz"))
+    m = VQDecoder(depth=2)
+    m.load_state_dict(weights.synth_like(m, seed=321))
+    m = m.to(DEV, dt).eval().requires_grad_(False)
+    tokens = [t.to(DEV) for t in torch.from_numpy(g["tokens"])]
+    out = ops.token_gather(tokens, codebook, out_dtype=dt)
+    rows = torch.from_numpy(g["rows"])
+    with torch.no_grad():
+        xrec = m.forward_padded(out["padded"], out["mask"])
+    e = _golden_rel(xrec[:, rows].float().cpu(), g["xrec_rows"])
+    print(f"VQDecoder {dt}: relL2 vs reference golden {e:.5f}")
+    assert xrec.shape == (4, 256, 768) and e < bar
+
+
 def _unet_inputs(B, h, w, seed=0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, 4, h, w, generator=g)

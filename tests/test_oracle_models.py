@@ -41,41 +41,22 @@ def test_oracle_token_decoder_matches_reference_golden(golden, decoder_sd):
     _check_against_golden(golden, prompt, pooled, atol=2e-5)
 
 
-def test_product_token_decoder_host_logic_matches_reference_golden(golden, decoder_sd):
-    # the token decoder is plain torch above the gather kernel, so its host logic can be checked on the CPU in fp32
-    from pigeon_amd.token_decoder import HighresVQDecoder
-    m = HighresVQDecoder(depth=2).eval()
-    m.load_state_dict(decoder_sd)
-    tokens = list(torch.from_numpy(golden["tokens"]))
-    emb, nums = ops_ref.token_gather_ref(tokens, weights.synth_codebook(), torch.float32)
-    with torch.no_grad():
-        prompt, pooled = m(emb, nums)                      # reference signature (packed rows + counts)
-        _check_against_golden(golden, prompt, pooled, atol=5e-5)
-        pad, mask = ops_ref.pad_and_mask_ref(emb, nums, pad_len=256)
-        prompt2, pooled2 = m.forward_padded(pad, mask)     # fixed-shape path fed by the gather kernel
-    _check_against_golden(golden, prompt2, pooled2, atol=5e-5)
-
-
-def test_lowres_vq_decoder_oracle_and_product_match_reference_golden(golden_dir):
-    # tests/golden/vq_decoder_lowres_depth2.npz: outputs of the reference's own VQDecoder (modeling_decoder.py:180-254)
+def test_lowres_vq_decoder_oracle_matches_reference_golden(golden_dir):
+    # tests/golden/vq_decoder_lowres_depth2.npz: outputs of the reference's own VQDecoder (modeling_decoder.py:180-254).
+    # (the PRODUCT decoders are checked against the same fixtures on the GPU: tests/test_gpu_models.py)
     from pigeon_amd.token_decoder import VQDecoder
     g = np.load(os.path.join(golden_dir, "vq_decoder_lowres_depth2.npz"))
-    m = VQDecoder(depth=2).eval()
+    with torch.device("meta"):
+        m = VQDecoder(depth=2)
     sd = weights.synth_like(m, seed=321)
-    m.load_state_dict(sd)
     tokens = list(torch.from_numpy(g["tokens"]))
     emb, nums = ops_ref.token_gather_ref(tokens, weights.synth_codebook(), torch.float32)
     assert nums.tolist() == g["token_nums"].tolist()
     rows = torch.from_numpy(g["rows"])
-    want_sum = g["xrec_sum"]
-    with torch.no_grad():
-        pad, mask = ops_ref.pad_and_mask_ref(emb, nums, pad_len=256)
-        outs = {"oracle": models_ref.token_decoder_forward(Policy(torch.float32), sd, emb, nums),
-                "product packed": m(emb, nums), "product padded": m.forward_padded(pad, mask)}
-    for what, xrec in outs.items():
-        assert xrec.shape == (4, 256, 768), what
-        assert np.allclose(xrec[:, rows].numpy(), g["xrec_rows"], atol=5e-5), what
-        assert np.allclose(xrec.double().sum(dim=(1, 2)).numpy(), want_sum, atol=5e-5 * xrec[0].numel() ** 0.5 * 4), what
+    xrec = models_ref.token_decoder_forward(Policy(torch.float32), sd, emb, nums)
+    assert xrec.shape == (4, 256, 768)
+    assert np.allclose(xrec[:, rows].numpy(), g["xrec_rows"], atol=5e-5)
+    assert np.allclose(xrec.double().sum(dim=(1, 2)).numpy(), g["xrec_sum"], atol=5e-5 * xrec[0].numel() ** 0.5 * 4)
 
 
 def test_build_tokenizer_decoder_reads_the_reference_file_layout(tmp_path):
@@ -186,6 +167,32 @@ def test_product_has_no_cpu_fallback():
         ops.attention(torch.zeros(1, 4, 64), torch.zeros(1, 4, 64), torch.zeros(1, 4, 64), 1)
     with pytest.raises(RuntimeError):
         ops.cfg_ddim_step(torch.zeros(2, 4), torch.zeros(1, 4), 7.0, 1, 1, 1, 1)
+    # ... and neither have the modules built on them: token decoder, CLIP tower, VAE decoder, UNet on CPU tensors raise
+    # instead of evaluating with torch ops
+    from pigeon_amd.clip_vision import CLIPVisionTransformer
+    from pigeon_amd.token_decoder import HighresVQDecoder, VQDecoder
+    from pigeon_amd.unet import UNet2DConditionModel
+    from pigeon_amd.vae import AutoencoderKL
+    with torch.no_grad():
+        for cls in (HighresVQDecoder, VQDecoder):
+            m = cls(depth=1).eval()
+            with pytest.raises(RuntimeError, match="no CPU fallback"):
+                m(torch.zeros(6, 32), torch.tensor([2, 4]))
+            with pytest.raises(RuntimeError, match="no CPU fallback"):
+                m.forward_padded(torch.zeros(2, 256, 32), torch.ones(2, 256))
+        vit = CLIPVisionTransformer(image_size=28, patch_size=14, width=64, layers=1, heads=2, output_dim=16).eval()
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            vit(torch.zeros(1, 3, 28, 28))
+        vae = AutoencoderKL(block_out_channels=(32, 64), layers_per_block=1).eval()
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            vae.decode(torch.zeros(1, 4, 8, 8))
+        unet = UNet2DConditionModel(block_out_channels=(32, 64), attention_head_dim=(1, 1), layers_per_block=1,
+                                    down_block_types=("DownBlock2D", "CrossAttnDownBlock2D"),
+                                    up_block_types=("CrossAttnUpBlock2D", "UpBlock2D"),
+                                    transformer_layers_per_block=1, cross_attention_dim=64).eval()
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            unet(torch.zeros(1, 4, 8, 8), 10, encoder_hidden_states=torch.zeros(1, 4, 64),
+                 added_cond_kwargs={"text_embeds": torch.zeros(1, 1280), "time_ids": torch.zeros(1, 6)})
 
 
 def test_threshold_sample_known_answers():
