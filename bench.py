@@ -13,8 +13,12 @@ over ranks with no collective in the loop; each rank all-gathers its final laten
 The JSON line carries, besides the driver's contract fields:
   roofline      the dominant hand-written kernel (MFMA attention): algorithmic FLOPs of every attention launch in the
                 timed region / their summed HIP-event durations (events recorded on the launch stream)
-  kernels       the same per kernel class (attention TFLOP/s; GroupNorm / step GB/s)
+  kernels       the same per kernel class (attention TFLOP/s; GroupNorm / LayerNorm / step ... GB/s with their fraction
+                of the 8 TB/s HBM peak)
   cpu_baseline  the oracle (fp32 torch CPU restatement, kind "port") timed on this box's host cores on a bounded sample
+                (token stage + 2 denoising steps, each reported; `cores` = threads torch actually ran)
+--config i selects the per-GPU share of BASELINE.json configs[i] (1: default; 2: 8 x 1216x832 x 50 steps; 3: 2 token
+sequences x 8 candidates; 4: 2048x2048), so an N-GPU driver run can use BASELINE's own multi-GPU workloads.
 """
 import argparse
 import json
@@ -29,6 +33,20 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# Per-GPU shares of BASELINE.json `configs`; configs[0] is the CPU case (the cpu_baseline leg)
+CONFIG_PRESETS = {
+    1: dict(batch=16, height=1024, width=1024, denoise_steps=25, num_return_images=1,
+            name="configs[1]: SER-30K-style sticker batch 16 per GPU, 1024x1024, 25 DDIM steps"),
+    2: dict(batch=8, height=1216, width=832, denoise_steps=50, num_return_images=1,
+            name="configs[2]: MovieLens-style poster batch 64 over 8 GPUs = 8 per GPU, 1216x832 (ratio 2:3), 50 DDIM steps"),
+    3: dict(batch=16, height=1024, width=1024, denoise_steps=25, num_return_images=8,
+            name="configs[3]: multi-candidate generation, 2 token sequences x 8 candidates = 16 images per GPU, "
+                 "1024x1024, 25 DDIM steps"),
+    4: dict(batch=2, height=2048, width=2048, denoise_steps=25, num_return_images=1,
+            name="configs[4]: high-resolution decode, 2x latent side (2048x2048 images, self-attention N = 16384), "
+                 "batch 2 per GPU, 25 DDIM steps"),
+}
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # HBM3E peak
@@ -79,12 +97,22 @@ class LaunchTimer:
         return agg
 
 
-def cpu_baseline(pipe, tokens, height, width, n_steps, guidance, threads):
-    """Oracle (fp32, CPU) on a bounded sample of configs[0]: the token stage + ONE of the n_steps denoising steps
-    (CFG pair) for one image, extrapolated to n_steps.  Returns images/sec."""
+def host_threads(requested):
+    """Threads the CPU baseline may use: the request, else OMP_NUM_THREADS (the box's CPU share), else the affinity
+    mask, never more than the CPUs this process may run on."""
+    allowed = len(os.sched_getaffinity(0))
+    want = requested or int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or allowed
+    return max(1, min(want, allowed)), allowed
+
+
+def cpu_baseline(pipe, tokens, height, width, n_steps, guidance, threads, timed_steps=2):
+    """Oracle (fp32, CPU) on a bounded sample of configs[0]: the token stage + `timed_steps` of the n_steps denoising
+    steps (CFG pair) for one image, each timed, extrapolated to n_steps with their mean.
+    Returns (images/sec, token-stage seconds, [seconds per timed step], threads actually used)."""
     from oracle import models_ref, ops_ref, pipeline_ref
     from oracle.models_ref import Policy
     torch.set_num_threads(threads)
+    threads = torch.get_num_threads()
     pol = Policy(torch.float32)
     f32 = lambda m: {k: v.detach().to("cpu", torch.float32) for k, v in m.state_dict().items()}
     unet_sd, dec_sd = f32(pipe.unet), f32(pipe.tokenizer_decoder)
@@ -101,13 +129,15 @@ def cpu_baseline(pipe, tokens, height, width, n_steps, guidance, threads):
         ids = torch.tensor([[width, height, 0, 0, width, height]], dtype=torch.float32).repeat(2, 1)
         ctx = torch.cat([torch.zeros_like(pe), pe])
         add = torch.cat([torch.zeros_like(pooled), pooled])
-        t0 = time.perf_counter()
-        t = sched.timesteps[0]
-        eps = models_ref.unet_forward(pol, unet_sd, cfg, torch.cat([lat] * 2), t, ctx, {"text_embeds": add, "time_ids": ids})
-        lat = sched.step(ops_ref.cfg_combine_ref(eps, guidance), t, lat)[0]
-        t_step = time.perf_counter() - t0
-    total = t_embed + n_steps * t_step
-    return 1.0 / total, t_embed, t_step
+        t_steps = []
+        for t in sched.timesteps[:timed_steps]:
+            t0 = time.perf_counter()
+            eps = models_ref.unet_forward(pol, unet_sd, cfg, torch.cat([lat] * 2), t, ctx,
+                                          {"text_embeds": add, "time_ids": ids})
+            lat = sched.step(ops_ref.cfg_combine_ref(eps, guidance), t, lat)[0]
+            t_steps.append(time.perf_counter() - t0)
+    total = t_embed + n_steps * sum(t_steps) / len(t_steps)
+    return 1.0 / total, t_embed, t_steps, threads
 
 
 def main():
@@ -115,15 +145,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (configs[1]: 16)")
-    ap.add_argument("--denoise-steps", type=int, default=25)
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIG_PRESETS),
+                    help="BASELINE.json configs[i] preset (per-GPU share); explicit flags below override it")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step")
+    ap.add_argument("--denoise-steps", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--guidance", type=float, default=7.0)
-    ap.add_argument("--num-return-images", type=int, default=1)
+    ap.add_argument("--num-return-images", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the CPU baseline (0: OMP_NUM_THREADS, else the affinity mask)")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="denoising steps the CPU baseline times (each reported)")
     ap.add_argument("--cross-kv-cache", action="store_true", help="reuse cross-attention K/V across denoising steps")
     ap.add_argument("--hip-graph", action="store_true",
                     help="replay the denoising loop as one hipGraph (pays when the loop is launch-bound: batch <= 2)")
@@ -131,6 +165,10 @@ def main():
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal of the multi-rank control flow on a one-GPU box: every rank uses cuda:0 (gloo only)")
     args = ap.parse_args()
+    preset = CONFIG_PRESETS[args.config]
+    for k in ("batch", "denoise_steps", "height", "width", "num_return_images"):
+        if getattr(args, k) is None:
+            setattr(args, k, preset[k])
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,7 +277,9 @@ def main():
             kernels[kind] = {"launches": n, "avg_us": secs / n * 1e6, "TFLOP/s": work / secs / 1e12,
                              "share_of_step": secs / (elapsed / args.steps)}
         else:
+            # HBM-bound kernels: algorithmic bytes / summed event time against the 8 TB/s HBM3E peak
             kernels[kind] = {"launches": n, "avg_us": secs / n * 1e6, "GB/s": work / secs / 1e9,
+                             "bound": "hbm", "peak_GB/s": PEAK_HBM_GBS, "frac": work / secs / 1e9 / PEAK_HBM_GBS,
                              "share_of_step": secs / (elapsed / args.steps)}
     roofline = None
     if "attention" in agg:
@@ -255,12 +295,16 @@ def main():
     state["phase"] = "cpu baseline"
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        ips, t_embed, t_step = cpu_baseline(pipe, [t.cpu() for t in tokens], args.height, args.width,
-                                            args.denoise_steps, args.guidance, args.cpu_threads)
-        cpu = {"value": ips, "unit": "images/sec", "cores": args.cpu_threads, "kind": "port",
-               "sample": f"configs[0]: 1 image {args.width}x{args.height} fp32, token stage ({t_embed:.1f} s) + 1 of "
-                         f"{args.denoise_steps} CFG denoising steps ({t_step:.1f} s) timed, extrapolated x{args.denoise_steps}; "
-                         "VAE excluded"}
+        threads, allowed = host_threads(args.cpu_threads)
+        ips, t_embed, t_steps, used = cpu_baseline(pipe, [t.cpu() for t in tokens], args.height, args.width,
+                                                   args.denoise_steps, args.guidance, threads, args.cpu_steps)
+        cpu = {"value": ips, "unit": "images/sec", "cores": used, "kind": "port",
+               "host_cpus_allowed": allowed, "token_stage_s": t_embed, "step_s": t_steps,
+               "extrapolated_total_s": 1.0 / ips,
+               "sample": f"configs[0]: 1 image {args.width}x{args.height} fp32 on {used} host threads, token stage "
+                         f"({t_embed:.1f} s) + {len(t_steps)} of {args.denoise_steps} CFG denoising steps timed "
+                         f"({', '.join(f'{x:.1f}' for x in t_steps)} s), extrapolated to {args.denoise_steps} steps "
+                         "with their mean; VAE excluded"}
 
     if rank == 0:
         line = {
@@ -268,11 +312,13 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"configs[1]: SER-30K-style sticker batch {args.batch} per GPU, {args.width}x{args.height}, "
-                                   f"{args.denoise_steps} DDIM steps with CFG {args.guidance}, bf16, synthetic tokens, "
+            "config": {"workload": f"{preset['name']} [as run: batch {args.batch} per GPU, {args.width}x{args.height}, "
+                                   f"{args.denoise_steps} DDIM steps, {args.num_return_images} image(s) per token "
+                                   f"sequence] with CFG {args.guidance}, bf16, synthetic tokens, "
                                    "random-init SDXL-shaped decoder (UNet 2.57B + token decoder 414M + VAE); "
                                    "end to end incl. VAE decode and uint8 copy to host",
-                       "batch_per_gpu": args.batch, "height": args.height, "width": args.width,
+                       "baseline_config": args.config, "batch_per_gpu": args.batch,
+                       "num_return_images": args.num_return_images, "height": args.height, "width": args.width,
                        "denoise_steps": args.denoise_steps, "parallelism": f"sample-sharded dp{world}"},
             # embeds + denoising loop only (no VAE decode / uint8 copy), this rank's GPU time per step
             "loop_only": {"images_per_sec_per_gpu": args.batch / (loop_ms * 1e-3) if loop_ms > 0 else None,

@@ -188,3 +188,25 @@ def test_scoring_stage_full_size_properties():
     other = scorer.score(images, feats.float().roll(1, 0), None, resize_hw=(512, 512))
     # (a random-init tower maps noise images to nearly parallel features: cos ~ 0.9986, still separable from 1)
     assert (other[:, 0] < 99.95).all() and torch.isnan(other[:, 1]).all()
+
+
+def test_config5_end_to_end_2048_through_generate_image(sdxl):
+    # BASELINE configs[4] through the whole facade: 2048x2048 images = 256x256 latents (self-attention over N = 16384 /
+    # 4096, GroupNorm rows of 65536 pixels, the VAE's 65536-token 512-wide head), batch 2, two DDIM steps, decoded to
+    # uint8.  Size-independent properties: finite latents, images that use the grey range, and sample independence (a
+    # sample alone reproduces its row of the batch of two up to the bf16 noise floor of another GEMM / conv algorithm).
+    toks = _tokens(2, 17)
+    noise = torch.randn(2, 4, 256, 256, generator=torch.Generator().manual_seed(123)).to(DEV)
+    kw = dict(width=2048, height=2048, num_inference_steps=2, guidance_scale_for_diffusion=7.0)
+    lat = {}
+    images, pe, pooled = sdxl.generate_image(image_tokens=toks, latents=noise, output_type="uint8",
+                                             callback=lambda i, t, x: lat.__setitem__(i, x.clone()), **kw)
+    assert images.shape == (2, 2048, 2048, 3) and images.dtype == torch.uint8
+    assert sorted(lat) == [0, 1] and lat[1].shape == (2, 4, 256, 256) and torch.isfinite(lat[1]).all()
+    assert pe.shape == (2, 256, 2048) and pooled.shape == (2, 1280)
+    assert images.float().std().item() > 1.0                       # not a constant image
+    alone = sdxl.generate_image(image_tokens=toks[1:], latents=noise[1:], output_type="latent", **kw)[0]
+    assert _rel(alone, lat[1][1:]) < 0.05 and _rel(alone, lat[1][:1]) > 0.5
+    # decoding is per sample: the image of sample 1 decoded alone equals its image in the batch (same kernels, chunk 1)
+    again = sdxl.decode_latents(lat[1][1:], "uint8")
+    assert (again.int() - images[1:].int()).abs().float().mean().item() < 1.0
