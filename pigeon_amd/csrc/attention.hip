@@ -22,6 +22,12 @@
 namespace {
 
 constexpr int ATT_BN = 64;       // keys per tile
+// The softmax reference of a 32-row block is raised (and O, l rescaled) only when a row maximum outgrows it by more
+// than 2^8: softmax is invariant to the reference, which merely has to keep exp2 in range (P <= 256: exact in fp32,
+// inside the bf16 / fp16 range; the accumulators are fp32).  With 32 rows per block SOME row sets a new maximum in most
+// tiles of iid scores, so an exact running maximum pays the O-wide rescale at almost every tile; deferred, it runs a
+// few times per row (+3...6 % on every SDXL shape, A/B in one process: scripts/attn_ab.py).
+constexpr float ATT_DEFER_LOG2 = 8.0f;
 // Head dims: the kernel is instantiated for a PADDED head dim DP of 64, 128 or 256 (256: one wavefront per SIMD, for
 // SD-1.5's 160-wide heads only); a head dim D < DP (D % 8 == 0: the token decoder's 88, SD-1.5's 40 / 80 / 160) is zero-filled up to DP on the way into registers / LDS (zero q and k columns
 // add nothing to the scores, zero v columns are never stored), so callers pass their tensors as they are.
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
     for (int d = 0; d < NOD; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = -1.0e30f;  // running max (raw score units without bias, exp2 units with bias)
+    float m_run = -1.0e30f;  // softmax reference (raw score units without bias, exp2 units with bias)
     float l_run = 0.f;       // this lane's half of the running denominator
 
     stage_load(0);
@@ -265,9 +271,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kb][r]);
         tmax = xhalf_max(tmax);
-        const float m_new = fmaxf(m_run, tmax);
         const float cm = HAS_BIAS ? 1.0f : a.c;
-        if (__any(m_new != m_run)) {
+        if (__any((tmax - m_run) * cm > ATT_DEFER_LOG2)) {
+            const float m_new = fmaxf(m_run, tmax);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cm);
             l_run *= alpha;
             const f32x2_t alpha2 = {alpha, alpha};
@@ -365,8 +371,232 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
     }
 }
 
+// =====================================================================================================================
+// The UNet's shape class (head dim 64, no key bias): 4 wavefronts x 64 query rows, K / V tiles by LDS-DMA.
+//   * a wavefront owns two 32-row query blocks: every K / V fragment read from LDS feeds two MFMAs (half the LDS read
+//     bytes per flop of the kernel above), a workgroup covers 256 rows (half the global -> LDS traffic per flop);
+//   * K / V tiles go global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write): each wave
+//     instruction fills 1 KiB of consecutive LDS; the swizzled K image and the sub-tiled V image of the kernel above
+//     are produced by permuting the per-lane SOURCE addresses; tile t+1 is in flight while tile t is computed, one
+//     barrier per tile;
+//   * two workgroups per CU (~230 VGPRs): the two query blocks of a wave are independent MFMA / VALU chains that the
+//     scheduler interleaves inside one wave.
+template <int DT>
+__global__ __launch_bounds__(256, 2) void pgn_attn_w64_kernel(AttnArgs a) {
+    constexpr int DP = 64, QB = 2;
+    constexpr int TILE_BYTES = ATT_BN * DP * 2;          // 8 KiB
+    constexpr int NKS = DP / 16, NOD = DP / 32;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE_BYTES];   // [buf][K | V]
+
+    const unsigned nwg = gridDim.x, orig = blockIdx.x;
+    const unsigned xcd = orig & 7u, qd = nwg >> 3, rm = nwg & 7u;
+    const unsigned wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    const int bh = (int)(wgid / (unsigned)a.nqt), qt = (int)(wgid % (unsigned)a.nqt);
+    const int b = bh / a.H, h = bh % a.H;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    int qrow[QB];
+    u16x8_t qf[QB][NKS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        qrow[qb] = qt * 256 + wid * 64 + qb * 32 + l31;
+        const int qrow_c = qrow[qb] < a.Nq ? qrow[qb] : a.Nq - 1;
+        const unsigned short* qp = a.q + b * a.q_sb + (long long)qrow_c * a.q_sn + h * a.q_sh + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) qf[qb][s] = *reinterpret_cast<const u16x8_t*>(qp + 16 * s);
+    }
+
+    const char* kbase = reinterpret_cast<const char*>(a.k + b * a.k_sb + h * a.k_sh);
+    const char* vbase = reinterpret_cast<const char*>(a.v + b * a.v_sb + h * a.v_sh);
+    const unsigned k_rowb = (unsigned)a.k_sn * 2u, v_rowb = (unsigned)a.v_sn * 2u;
+    const int nt = (a.Nk + ATT_BN - 1) / ATT_BN;
+    const int rem = a.Nk - (nt - 1) * ATT_BN;            // keys of the last tile (1..64)
+
+    // LDS-DMA: wave w, instruction i fills the 16-byte slots [(2 w + i) 64, +64) of a tile image; a lane supplies the
+    // (row, chunk) whose image position its slot is.  Rows past the end of a ragged last tile re-read its last row
+    // (their scores are masked to -inf, so their probabilities are exactly 0 and V's content does not matter).
+    unsigned ksrc[2], vsrc[2], ksrc_last[2], vsrc_last[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int slot = (wid * 2 + i) * 64 + lane;
+        const int krow = slot >> 3, kch = (slot & 7) ^ ((krow >> 1) & 7);                 // inverse of k_lds_off<64>
+        const int vrow = ((slot >> 6) << 3) | ((slot >> 2) & 7), vch = (((slot >> 5) & 1) << 2) | (slot & 3);  // of v_lds_off
+        ksrc[i] = (unsigned)krow * k_rowb + (unsigned)kch * 16u;
+        vsrc[i] = (unsigned)vrow * v_rowb + (unsigned)vch * 16u;
+        ksrc_last[i] = (unsigned)min(krow, rem - 1) * k_rowb + (unsigned)kch * 16u;
+        vsrc_last[i] = (unsigned)min(vrow, rem - 1) * v_rowb + (unsigned)vch * 16u;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto load_tile = [&](int t, int buf) __attribute__((always_inline)) {
+        const char* gk = kbase + (size_t)t * ATT_BN * k_rowb;
+        const char* gv = vbase + (size_t)t * ATT_BN * v_rowb;
+        unsigned char* l = smem + buf * (2 * TILE_BYTES) + wid * 2048;
+        const bool last = t == nt - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(gk + (last ? ksrc_last[i] : ksrc[i])), (lptr_t)(l + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(gv + (last ? vsrc_last[i] : vsrc[i])),
+                                             (lptr_t)(l + TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+
+    int k_roff[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) k_roff[s] = k_lds_off<DP>(l31, 2 * s + hh);    // + 4096 for key block 1
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int v_lane_off = 64 * (i16 >> 2) + 32 * g16 + 8 * (i16 & 3);
+
+    f32x16_t oacc[QB][NOD];
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int d = 0; d < NOD; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
+        m_run[qb] = -1.0e30f;
+        l_run[qb] = 0.f;
+    }
+    const f32x2_t c2 = {a.c, a.c};
+
+    load_tile(0, 0);
+    __syncthreads();
+
+    auto tile = [&](int t, auto masked_tag, auto buf_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr int BUF = decltype(buf_tag)::value;
+        if (t + 1 < nt) load_tile(t + 1, BUF ^ 1);        // its last readers passed the barrier of tile t-1
+        const unsigned char* kt = smem + BUF * (2 * TILE_BYTES);
+        const unsigned char* vt = kt + TILE_BYTES;
+
+        f32x16_t sacc[QB][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[qb][kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                const u16x8_t kf = *reinterpret_cast<const u16x8_t*>(kt + kb * 4096 + k_roff[s]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = mfma32<DT>(kf, qf[qb][s], sacc[qb][kb]);
+            }
+        }
+
+        u16x8_t pf[QB][2][2];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if constexpr (MASKED) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= rem) sacc[qb][kb][r] = -INFINITY;
+            }
+            // online softmax with a deferred reference (see pgn_attn_fwd_kernel)
+            float tmax = sacc[qb][0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qb][kb][r]);
+            tmax = xhalf_max(tmax);
+            if (__any((tmax - m_run[qb]) * a.c > ATT_DEFER_LOG2)) {
+                const float m_new = fmaxf(m_run[qb], tmax);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * a.c);
+                l_run[qb] *= alpha;
+                const f32x2_t alpha2 = {alpha, alpha};
+#pragma unroll
+                for (int d = 0; d < NOD; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2_t o2 = {oacc[qb][d][r], oacc[qb][d][r + 1]};
+                        o2 *= alpha2;
+                        oacc[qb][d][r] = o2[0];
+                        oacc[qb][d][r + 1] = o2[1];
+                    }
+                m_run[qb] = m_new;
+            }
+            const float mc = m_run[qb] * a.c;
+            const f32x2_t nmc2 = {-mc, -mc};
+            f32x2_t lsum2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2_t x = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
+                    x = x * c2 + nmc2;
+                    f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    lsum2[(r >> 1) & 1] += p;
+                    pf[qb][kb][r >> 3][r & 7] = Cvt<DT>::from_f32(p[0]);
+                    pf[qb][kb][r >> 3][(r & 7) + 1] = Cvt<DT>::from_f32(p[1]);
+                }
+            lsum2[0] += lsum2[1];
+            l_run[qb] += lsum2[0][0] + lsum2[0][1];
+        }
+
+#pragma unroll
+        for (int d = 0; d < NOD; ++d)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int key0 = kb * 32 + 16 * s2 + 4 * hh;
+                    const int off0 = (16 * DP) * (key0 >> 3) + 64 * (key0 & 7) + 512 * d + v_lane_off;
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(vt + off0));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(vt + off0 + 16 * DP));
+                    u16x8_t vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = mfma32<DT>(vf, pf[qb][kb][s2], oacc[qb][d]);
+                }
+        __syncthreads();                                   // tile t+1 has landed (vmcnt) and tile t is free to refill
+    };
+
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    const bool ragged = rem < ATT_BN;
+    const int nfull = ragged ? nt - 1 : nt;
+    int t = 0;
+    for (; t + 1 < nfull; t += 2) {
+        tile(t, std::false_type{}, B0{});
+        tile(t + 1, std::false_type{}, B1{});
+    }
+    if (t < nfull) {
+        tile(t, std::false_type{}, B0{});
+        if (ragged) tile(nt - 1, std::true_type{}, B1{});
+    } else if (ragged) {
+        tile(nt - 1, std::true_type{}, B0{});
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = xhalf_sum(l_run[qb]);
+        const float inv = 1.0f / l_tot;
+        if (qrow[qb] < a.Nq) {
+            unsigned short* op = a.o + b * a.o_sb + (long long)qrow[qb] * a.o_sn + h * a.o_sh;
+#pragma unroll
+            for (int d = 0; d < NOD; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    u16x4_t w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = Cvt<DT>::from_f32(oacc[qb][d][4 * g4 + j] * inv);
+                    *reinterpret_cast<u16x4_t*>(op + d * 32 + 8 * g4 + 4 * hh) = w;
+                }
+        }
+    }
+}
+
 #ifdef PGN_TUNING_HOOKS
-int g_attn_variant = 0;  // 0 = shipped geometry, 1 = force 8 waves (256 query rows per workgroup)
+int g_attn_variant = 0;  // 0 = shipped heuristic, 1 = 4 waves x 32 rows, 3 = 4 waves x 64 rows (LDS-DMA), 16 = 8 waves x 32 rows
 #else
 constexpr int g_attn_variant = 0;
 #endif
@@ -396,14 +626,21 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     if (key_bias != nullptr && bias_sb < 0) return PGN_ERR_INVALID;
     // the kernel addresses a (batch, head) key / value slice with 32-bit byte offsets
     if (((int64_t)Nk + 2 * ATT_BN) * (k_sn > v_sn ? k_sn : v_sn) * 2 >= (int64_t)1 << 32) return PGN_ERR_UNSUPPORTED;
-    // Geometry: 4 waves x 32 rows, three workgroups per CU at head dim 64 (two at 128, one at 256): the waves of a
+    // Head dim 64 without a key bias and with long sequences (the UNet's level-1 self-attention, N = 4096, and everything
+    // at higher resolution): pgn_attn_w64_kernel, 4 waves x 64 rows with LDS-DMA staging - 995 vs 925 TFLOP/s at
+    // N = 4096; on short key loops (N = 1024: 809 vs 827, cross-attention Nk = 256: 543-608 vs 573-637) its 256-row
+    // workgroups have too little to amortise their prologue over and the 32-row kernel stays.
+    // Otherwise: 4 waves x 32 rows, three workgroups per CU at head dim 64 (two at 128, one at 256): the waves of a
     // SIMD come from DIFFERENT workgroups, so one workgroup's barrier / prologue / epilogue hides behind the others'
     // main loops.  Measured on MI355X at every
     // SDXL shape (scripts/bench_kernels.py): 4 waves beat the 8-wave 256-row geometry by 4 % (self, N 4096) to
     // 30 % (cross, Nk 256); the 8-wave form is compiled into the measurement build only (PGN_TUNING_HOOKS).
     int nw = 4;
-    if (g_attn_variant == 1 && D == 64) nw = 8;
-    const int bm = nw * 32;
+    bool w64 = D == 64 && key_bias == nullptr && Nk >= 2048 && Nq >= 1024;
+    if (g_attn_variant == 16 && D == 64) nw = 8;
+    if (g_attn_variant == 1 || nw == 8) w64 = false;
+    if (g_attn_variant == 3) w64 = D == 64 && key_bias == nullptr;
+    const int bm = w64 ? 256 : nw * 32;
     const long long nqt = (Nq + bm - 1) / bm;
     const long long blocks = (long long)B * H * nqt;
     if (blocks > 0x7fffffffLL) return PGN_ERR_UNSUPPORTED;
@@ -425,7 +662,8 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
 #endif
 #define PGN_ATT_LAUNCH(DT, BIAS)                                                                                  \
     do {                                                                                                          \
-        if (D == 64) {                                                                                            \
+        if (w64) hipLaunchKernelGGL((pgn_attn_w64_kernel<DT>), grid, block, 0, s, a);                             \
+        else if (D == 64) {                                                                                       \
             PGN_ATT_LAUNCH_8W(DT, BIAS)                                                                           \
             hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 3, 64, false>), grid, block, 0, s, a);             \
         } else if (D < 64) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 3, 64, true>), grid, block, 0, s, a); \
