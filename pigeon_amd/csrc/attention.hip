@@ -86,6 +86,37 @@ __device__ __forceinline__ int v_lds_off(int row, int ch) {
     return (16 * DP) * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * (ch & 3);
 }
 
+// Epilogue of one 32-row query block at head dim 64: the lane-per-row accumulators (lane = row l31, half hh: four
+// consecutive dims per register group) are normalised, rounded and written to a [32 rows][144 bytes] LDS image of the
+// wavefront, then stored as WHOLE 128-byte rows, 16 bytes per lane (8 rows per store instruction).  Per-lane stores at a
+// row stride touch 32 cache lines with 8 bytes each and made the epilogue store-issue-bound (short key loops: the
+// epilogue was 15-20 % of a workgroup's life).  `lds` is private to the wavefront; the caller has passed the barrier
+// that ends the last tile, so the K / V images are dead.
+constexpr int ATT_O_PITCH = 144;   // 128-byte rows + 16: 16-byte aligned for ds_read_b128, rows 8 apart share a bank pair
+template <int DT>
+__device__ __forceinline__ void att_store_block_d64(unsigned char* lds, const f32x16_t (&oacc)[2], float inv,
+                                                    unsigned short* orow0, long long o_sn, int rows_valid, int lane) {
+    const int l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            u16x4_t w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = Cvt<DT>::from_f32(oacc[d][4 * g4 + j] * inv);
+            *reinterpret_cast<u16x4_t*>(lds + l31 * ATT_O_PITCH + (d * 32 + 8 * g4 + 4 * hh) * 2) = w;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows are read back by other lanes of this wavefront
+    const int r8 = lane >> 3, ch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 8 + r8;
+        const u16x8_t v = *reinterpret_cast<const u16x8_t*>(lds + row * ATT_O_PITCH + ch * 16);
+        if (row < rows_valid) *reinterpret_cast<u16x8_t*>(orow0 + (long long)row * o_sn + ch * 8) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // before the image is overwritten by the next block
+}
+
 template <int DT, bool HAS_BIAS, int NWAVES, int MINW, int DP, bool PAD>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArgs a) {
     constexpr int ATT_THREADS = NWAVES * 64;
@@ -356,7 +387,11 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
     // ---- epilogue: normalise and store (lane owns row qrow; 4 consecutive dims per 8-byte store)
     const float l_tot = xhalf_sum(l_run);
     const float inv = 1.0f / l_tot;
-    if (qrow < a.Nq) {
+    if constexpr (DP == 64 && !PAD) {
+        const int row0 = qt * ATT_BM + wid * 32;                      // wave-uniform
+        att_store_block_d64<DT>(smem + wid * (32 * ATT_O_PITCH), oacc, inv,
+                                a.o + b * a.o_sb + (long long)row0 * a.o_sn + h * a.o_sh, a.o_sn, a.Nq - row0, lane);
+    } else if (qrow < a.Nq) {
         unsigned short* op = a.o + b * a.o_sb + (long long)qrow * a.o_sn + h * a.o_sh;
 #pragma unroll
         for (int d = 0; d < NOD; ++d)
@@ -580,18 +615,9 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64_kernel(AttnArgs a) {
     for (int qb = 0; qb < QB; ++qb) {
         const float l_tot = xhalf_sum(l_run[qb]);
         const float inv = 1.0f / l_tot;
-        if (qrow[qb] < a.Nq) {
-            unsigned short* op = a.o + b * a.o_sb + (long long)qrow[qb] * a.o_sn + h * a.o_sh;
-#pragma unroll
-            for (int d = 0; d < NOD; ++d)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    u16x4_t w;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) w[j] = Cvt<DT>::from_f32(oacc[qb][d][4 * g4 + j] * inv);
-                    *reinterpret_cast<u16x4_t*>(op + d * 32 + 8 * g4 + 4 * hh) = w;
-                }
-        }
+        const int row0 = qt * 256 + wid * 64 + qb * 32;               // wave-uniform
+        att_store_block_d64<DT>(smem + wid * (32 * ATT_O_PITCH), oacc[qb], inv,
+                                a.o + b * a.o_sb + (long long)row0 * a.o_sn + h * a.o_sh, a.o_sn, a.Nq - row0, lane);
     }
 }
 
@@ -626,17 +652,17 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     if (key_bias != nullptr && bias_sb < 0) return PGN_ERR_INVALID;
     // the kernel addresses a (batch, head) key / value slice with 32-bit byte offsets
     if (((int64_t)Nk + 2 * ATT_BN) * (k_sn > v_sn ? k_sn : v_sn) * 2 >= (int64_t)1 << 32) return PGN_ERR_UNSUPPORTED;
-    // Head dim 64 without a key bias and with long sequences (the UNet's level-1 self-attention, N = 4096, and everything
-    // at higher resolution): pgn_attn_w64_kernel, 4 waves x 64 rows with LDS-DMA staging - 995 vs 925 TFLOP/s at
-    // N = 4096; on short key loops (N = 1024: 809 vs 827, cross-attention Nk = 256: 543-608 vs 573-637) its 256-row
-    // workgroups have too little to amortise their prologue over and the 32-row kernel stays.
+    // Head dim 64 without a key bias and with at least 16 key tiles (the UNet's self-attention: N = 4096 and 1024, and
+    // everything at higher resolution): pgn_attn_w64_kernel, 4 waves x 64 rows with LDS-DMA staging - 1003 vs 922 TFLOP/s
+    // at N = 4096, 852 vs 812 at N = 1024; on the 4-tile key loop of cross-attention (Nk = 256) its 256-row workgroups
+    // have too little to amortise their prologue over (592-653 vs 600-660) and the 32-row kernel stays.
     // Otherwise: 4 waves x 32 rows, three workgroups per CU at head dim 64 (two at 128, one at 256): the waves of a
     // SIMD come from DIFFERENT workgroups, so one workgroup's barrier / prologue / epilogue hides behind the others'
     // main loops.  Measured on MI355X at every
     // SDXL shape (scripts/bench_kernels.py): 4 waves beat the 8-wave 256-row geometry by 4 % (self, N 4096) to
     // 30 % (cross, Nk 256); the 8-wave form is compiled into the measurement build only (PGN_TUNING_HOOKS).
     int nw = 4;
-    bool w64 = D == 64 && key_bias == nullptr && Nk >= 2048 && Nq >= 1024;
+    bool w64 = D == 64 && key_bias == nullptr && Nk >= 1024 && Nq >= 512;
     if (g_attn_variant == 16 && D == 64) nw = 8;
     if (g_attn_variant == 1 || nw == 8) w64 = false;
     if (g_attn_variant == 3) w64 = D == 64 && key_bias == nullptr;

@@ -254,6 +254,10 @@ ATTN_CASES = [
     (3, 2, 1, 1, torch.bfloat16, False),
     (2, 3, 257, 65, torch.float16, False),
     (2, 8, 1024, 256, torch.bfloat16, True),      # lowres-style encoder_attention_mask
+    # the 64-rows-per-wave LDS-DMA kernel (head dim 64, no bias, Nk >= 1024, Nq >= 512): ragged on both sides, fp16
+    (1, 2, 1000, 1100, torch.bfloat16, False),
+    (1, 3, 1024, 1536, torch.float16, False),
+    (2, 2, 520, 1025, torch.bfloat16, False),     # one key in the last tile, 8 rows in the last workgroup
 ]
 
 
@@ -297,6 +301,25 @@ def test_attention_strided_inputs_and_rescale_branch(ops):
     dq = qkv.to(DEV)
     got = ops.attention(dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:], H).cpu().float()
     assert (got - want).abs().max().item() < 2.0 ** -7 * max(1.0, want.abs().max().item())
+
+
+def test_attention_rescale_branch_of_the_64_row_kernel(ops):
+    # same late-spike construction on a shape the 64-rows-per-wave kernel takes (Nk >= 1024): the deferred softmax
+    # reference (raised only when a row maximum outgrows it by 2^8) must be raised in a late tile for SOME rows of a
+    # block (key 1500 aligned with queries 17 and 300) and left alone for moderate growth (key 700, query 40)
+    B, H, N = 2, 3, 1600
+    C = H * 64
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(torch.bfloat16)
+    qkv[:, 1500, C:2 * C] = (qkv[:, 17, 0:C].float() * 2.5 + qkv[:, 300, 0:C].float() * 2.5).to(torch.bfloat16)
+    qkv[:, 700, C:2 * C] = qkv[:, 40, 0:C] * 0.5
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    want = ops_ref.attention_ref(q, k, v, H).float()
+    dq = qkv.to(DEV)
+    got = ops.attention(dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:], H).cpu().float()
+    assert (got - want).abs().max().item() < 2.0 ** -7 * max(1.0, want.abs().max().item())
+    # the spike really dominates rows 17 and 300 (their output is close to V row 1500), i.e. the branch was exercised
+    assert (want[:, 17] - v[:, 1500].float()).abs().max().item() < 0.25
 
 
 def test_attention_full_size_properties(ops):
