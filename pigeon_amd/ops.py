@@ -567,5 +567,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
                                    _ptr(key_bias), Nk if key_bias is not None else 0, scale, _stream())
         _lib.check(rc, "pgn_attention_fwd")
 
-    _launch("attention" if D == 64 else f"attention_d{D}", work, run)
+    # timing class = the kernel the library picks (pgn_attention_fwd's heuristic, attention.hip): head dim 64 without a
+    # bias and with >= 16 key tiles goes to the 64-rows-per-wave LDS-DMA kernel
+    if D != 64:
+        kind = f"attention_d{D}"
+    elif key_bias is None and Nk >= 1024 and Nq >= 512:
+        kind = "attention_w64"
+    else:
+        kind = "attention"
+    _launch(kind, work, run)
     return out
