@@ -79,6 +79,27 @@ int pgn_token_gather(const int64_t* ids, const int32_t* offsets, int B, const fl
                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Token gather carried on into the token decoder's first layer: the rows pgn_token_gather would write as
+ * out_padded go through `in_proj`, padding rows are zeroed, `pos_embed` is added, and the additive key
+ * bias of the decoder's cross-attention is emitted - two launches for what HighresVQDecoder.forward /
+ * VQDecoder.forward do in Pigeon/models/modeling_decoder.py:310-319 (pad loop, `self.in_proj(x) * mask`,
+ * `+ self.pos_embed`) and :100-101 (`(1 - mask) * -10000`).
+ *
+ * ids / offsets / codebook / id_offset / max_tokens / token_nums / status   as for pgn_token_gather; dim <= 64
+ * dtype           PGN_BF16 or PGN_F16: type of in_proj_weight, in_proj_bias, pos_embed and out
+ * in_proj_weight  dtype [E, dim]   (nn.Linear layout)          in_proj_bias  dtype [E] or NULL
+ * pos_embed       dtype [>= pad_len, E]
+ * out             dtype [B, pad_len, E]   OUT: round(round(x_row . W^T + b) * mask + pos_embed)
+ * key_bias        fp32  [B, pad_len]      OUT, may be NULL: 0 for kept tokens, -10000 for padding
+ * Rounding points are the reference's (16-bit rows, fp32 dot + bias, 16-bit GEMM output, 16-bit sum); only the
+ * order of the fp32 dot differs from a library GEMM's, so results agree to 1 ulp of the 16-bit type.
+ */
+int pgn_token_embed(const int64_t* ids, const int32_t* offsets, int B, const float* codebook, int num_codes,
+                    int dim, int64_t id_offset, int max_tokens, int dtype, const void* in_proj_weight,
+                    const void* in_proj_bias, const void* pos_embed, int E, int64_t* token_nums, void* out,
+                    float* key_bias, int pad_len, int32_t* status, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused classifier-free-guidance combine + DDIM step (eta = 0).
  * Replaces lavit_for_pigeon.py:760-764: `chunk(2)`, `eps_u + g*(eps_t - eps_u)` and
  * diffusers 0.27.2 DDIMScheduler.step(...).prev_sample.
@@ -211,6 +232,20 @@ int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, in
                       int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn,
                       int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
                       int64_t o_sh, const float* key_bias, int64_t bias_sb, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Causal multi-head self-attention over a short sequence: out[i] = softmax_{j <= i}(q_i . k_j * scale) v_j.
+ * Replaces the `attn_mask` form of nn.MultiheadAttention inside open_clip's text Transformer, reached from
+ * `self.model.encode_text(texts)` at Evaluation/eval_utils.py:126 (CLIPScore.calculate_clip_score; ViT-H-14 text tower:
+ * 77 tokens, 16 heads x 64, upper-triangular -inf mask).  Layout and strides as for pgn_attention_fwd
+ * (q / k / v / out [B, N, H, D], element strides, last dim contiguous).  N <= 128, D even and <= 128, bf16 / f16;
+ * otherwise PGN_ERR_UNSUPPORTED.  Latency-bound (0.4 GFLOP per call at batch 16): one workgroup per (batch, head),
+ * fp32 dot products and probabilities, output rounded once.
+ */
+int pgn_attention_causal_fwd(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H, int N,
+                             int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn,
+                             int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
+                             int64_t o_sh, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row softmax of materialised attention scores:  probs[m, :] = softmax(scale * scores[m, :]).

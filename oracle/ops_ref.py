@@ -149,6 +149,21 @@ def attention_ref(q, k, v, heads, scale=None, key_bias=None, out_dtype=None):
     return o.to(out_dtype or q.dtype)
 
 
+def causal_attention_ref(q, k, v, heads, scale=None, out_dtype=None):
+    """nn.MultiheadAttention with open_clip's `attn_mask` (upper triangle -inf, text Transformer): key j reaches query
+    i only for j <= i.  fp32 softmax / accumulate over the given inputs, output rounded once."""
+    B, N, C = q.shape
+    D = C // heads
+    scale = D ** -0.5 if scale is None else scale
+    qh = q.float().view(B, N, heads, D).transpose(1, 2)
+    kh = k.float().view(B, N, heads, D).transpose(1, 2)
+    vh = v.float().view(B, N, heads, D).transpose(1, 2)
+    s = torch.matmul(qh, kh.transpose(-1, -2)) * scale
+    s = s + torch.full((N, N), float("-inf")).triu_(1)
+    o = torch.matmul(torch.softmax(s, dim=-1), vh).transpose(1, 2).reshape(B, N, C)
+    return o.to(out_dtype or q.dtype)
+
+
 # ---- transformer-block row kernels -------------------------------------------------------------------------
 def geglu_ref(h: torch.Tensor) -> torch.Tensor:
     """diffusers 0.27.2 GEGLU.forward after the projection: `hidden, gate = h.chunk(2, dim=-1); hidden * F.gelu(gate)`,

@@ -5,13 +5,16 @@
 line by line.  `clip_vision_forward` restates open_clip's VisionTransformer.forward (`model.encode_image`, reached from
 eval_utils.py:120,541) over a plain state dict with open_clip's parameter names.  PARITY UNPINNED for the tower:
 open_clip is a third-party wheel absent from /root/reference and this image, and the reference holds no fixture for it;
-the score arithmetic is pinned by closed-form known answers (tests/test_scoring.py).
+the score arithmetic is pinned by closed-form known answers (tests/test_scoring.py).  `clip_text_forward` restates
+open_clip's `CLIP.encode_text` (eval_utils.py:126) the same way, equally unpinned; the BPE tokenizer is cross-checked
+against transformers' independent CLIPTokenizer on a synthetic merges table (tests/test_clip_text.py).
 """
 from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F
 
+from . import ops_ref
 from .models_ref import SD, Policy
 
 
@@ -63,3 +66,31 @@ def clip_vision_forward(p: Policy, sd_in: Dict[str, torch.Tensor], heads: int, p
         i += 1
     pooled = ln(x[:, 0], "ln_post")
     return pooled.to(p.compute) @ sd["proj"].to(p.compute)
+
+
+def clip_text_forward(p: Policy, sd_in: Dict[str, torch.Tensor], heads: int, text: torch.Tensor):
+    """open_clip CLIP.encode_text(text, normalize=False): token + positional embeddings, causal pre-norm Transformer,
+    ln_final, the row at the end-of-text token (the highest id: `text.argmax(-1)`), `text_projection`."""
+    sd = SD(sd_in)
+    c = p.compute
+    L = text.shape[1]
+    x = sd["token_embedding.weight"].to(c)[text] + sd["positional_embedding"].to(c)[:L]
+    ln = lambda t, pre: p.layer_norm(t, sd[pre + ".weight"], sd[pre + ".bias"], 1e-5).to(t.dtype)
+    W = x.shape[-1]
+    D = W // heads
+    i = 0
+    while sd.has(f"transformer.resblocks.{i}."):
+        pre = f"transformer.resblocks.{i}."
+        h = ln(x, pre + "ln_1")
+        qkv = p.lin(h, sd[pre + "attn.in_proj_weight"], sd[pre + "attn.in_proj_bias"])
+        q, k, v = qkv.chunk(3, dim=-1)
+        o = ops_ref.causal_attention_ref(q.to(c), k.to(c), v.to(c), heads, D ** -0.5, out_dtype=c)
+        x = x + p.lin(o, sd[pre + "attn.out_proj.weight"], sd[pre + "attn.out_proj.bias"])
+        h = ln(x, pre + "ln_2")
+        m = p.lin(F.gelu(p.lin(h, sd[pre + "mlp.c_fc.weight"], sd[pre + "mlp.c_fc.bias"])),
+                  sd[pre + "mlp.c_proj.weight"], sd[pre + "mlp.c_proj.bias"])
+        x = x + m
+        i += 1
+    x = ln(x, "ln_final")
+    pooled = x[torch.arange(x.shape[0]), text.argmax(dim=-1)]
+    return pooled.to(c) @ sd["text_projection"].to(c)

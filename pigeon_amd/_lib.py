@@ -24,6 +24,7 @@ SIGNATURES = {
     "pgn_error_string": (_c.c_char_p, [_i]),
     "pgn_workspace_bytes": (_c.c_size_t, [_i]),
     "pgn_token_gather": (_i, [_vp, _vp, _i, _vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "pgn_token_embed": (_i, [_vp, _vp, _i, _vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "pgn_cfg_ddim_step": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _f, _f, _f, _f, _f, _i, _u, _f, _vp]),
     "pgn_cfg_euler_step": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i64, _f, _f, _f, _i, _u, _vp]),
     "pgn_cfg_expand_scale": (_i, [_vp, _i, _vp, _i, _i64, _f, _vp]),
@@ -45,6 +46,7 @@ SIGNATURES = {
     "pgn_add_layernorm_cb": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _f, _vp]),
     "pgn_image_to_uint8": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "pgn_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [_i64] * 12 + [_vp, _i64, _f, _vp]),
+    "pgn_attention_causal_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_i64] * 12 + [_f, _vp]),
 }
 
 _lib = None

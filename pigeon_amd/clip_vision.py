@@ -11,12 +11,11 @@ loads after stripping the prefix): conv1 14x14/14 patch embedding, class token, 
 32 pre-norm residual blocks (fused-qkv nn.MultiheadAttention, GELU MLP), ln_post on the class token, `proj`.
 On the GPU the 16 x 80-wide attention heads run in the HIP MFMA kernel (pgn_attention_fwd, head dim zero-filled to
 128 in-kernel, q/k/v consumed in place from the fused qkv projection), the LayerNorms (+ residual adds) in
-pgn_add_layernorm, the scores in pgn_clip_scores; GEMMs on hipBLASLt.  Called on CPU tensors (host-logic tests) the
-same module evaluates with torch ops.
+pgn_add_layernorm, the scores in pgn_clip_scores; GEMMs on hipBLASLt.  CPU tensors raise (no torch fallback).
 
-Out of scope (stated, not built): the CLIP TEXT tower and its BPE tokenizer — target-text features are per-item
-constants of the dataset, cached the way the reference caches `*_hist_embeds.npy` (cal_scores.py:73-99); callers pass
-them as `text_features`.
+The text side (tokenizer + text tower, eval_utils.py:115,126) is pigeon_amd/clip_text.py; `CLIPScorer` takes both
+optionally, so target texts can be passed as strings (`texts=`) or, as before, as cached features (`text_features=`,
+the way the reference caches `*_hist_embeds.npy`, cal_scores.py:73-99).
 """
 import os
 from typing import Dict, Optional, Sequence, Tuple
@@ -49,12 +48,13 @@ class _MHA(nn.Module):
         self.out_proj = nn.Linear(width, width)
         nn.init.normal_(self.in_proj_weight, std=width ** -0.5)
 
-    def forward(self, x):
+    def forward(self, x, causal: bool = False):
         B, N, C = x.shape
         qkv = F.linear(x, self.in_proj_weight, self.in_proj_bias)          # [B, N, 3C] = [q | k | v]
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         D = C // self.heads
-        return self.out_proj(ops.attention(q, k, v, self.heads, D ** -0.5))      # pgn_attention_fwd (head dim 80)
+        # image tower: pgn_attention_fwd (head dim 80); text tower: pgn_attention_causal_fwd (77 tokens, head dim 64)
+        return self.out_proj(ops.attention(q, k, v, self.heads, D ** -0.5, causal=causal))
 
 
 class _MLP(nn.Module):
@@ -165,12 +165,28 @@ def clip_preprocess(images_u8: torch.Tensor, resize_hw: Optional[Tuple[int, int]
 class CLIPScorer:
     """Per-image (tgt_score, hist_score) for a batch of generated images, all on one GPU."""
 
-    def __init__(self, vision: CLIPVisionTransformer, device="cuda", model_dtype=torch.bfloat16, batch_size: int = 64):
+    def __init__(self, vision: CLIPVisionTransformer, device="cuda", model_dtype=torch.bfloat16, batch_size: int = 64,
+                 text=None, tokenizer=None):
+        """`text` / `tokenizer`: a clip_text.CLIPTextTransformer and SimpleTokenizer (eval_utils.py:114-115 builds both
+        halves of one checkpoint); without them target texts must come in as precomputed `text_features`."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("CLIPScorer runs on an MI355X (device 'cuda:N'); there is no CPU path")
         self.vision = vision.to(self.device, model_dtype).eval().requires_grad_(False)
+        self.text = None if text is None else text.to(self.device, model_dtype).eval().requires_grad_(False)
+        self.tokenizer = tokenizer
         self.batch_size = batch_size                                      # cal_scores.py:47
+
+    @torch.no_grad()
+    def encode_text(self, texts: Sequence[str]) -> torch.Tensor:
+        """eval_utils.py:126 (`self.model.encode_text(self.tokenizer(texts))`) -> [len(texts), output_dim]."""
+        if self.text is None or self.tokenizer is None:
+            raise RuntimeError("CLIPScorer was built without a text tower / tokenizer: pass text_features instead")
+        feats = []
+        for i in range(0, len(texts), self.batch_size):
+            tokens = self.tokenizer(list(texts[i:i + self.batch_size])).to(self.device)
+            feats.append(self.text(tokens))
+        return torch.cat(feats, dim=0)
 
     @torch.no_grad()
     def encode_image(self, images_u8: torch.Tensor, resize_hw=None) -> torch.Tensor:
@@ -183,9 +199,15 @@ class CLIPScorer:
 
     @torch.no_grad()
     def score(self, images_u8, text_features: Optional[torch.Tensor] = None,
-              history_features: Optional[torch.Tensor] = None, resize_hw=None) -> torch.Tensor:
+              history_features: Optional[torch.Tensor] = None, resize_hw=None,
+              texts: Optional[Sequence[str]] = None) -> torch.Tensor:
         """-> fp32 [M, 2] = (tgt_score, hist_score); a column without its inputs is NaN.  `images_u8`: uint8
-        [M, H, W, 3] tensor, or the list of equally sized PIL images generate_image returns."""
+        [M, H, W, 3] tensor, or the list of equally sized PIL images generate_image returns.  `texts`: one target
+        text per image, encoded here (needs the text tower); alternative to `text_features`."""
+        if texts is not None:
+            if text_features is not None:
+                raise ValueError("pass texts or text_features, not both")
+            text_features = self.encode_text(texts)
         if not isinstance(images_u8, torch.Tensor):
             import numpy as np
             images_u8 = torch.from_numpy(np.stack([np.asarray(im.convert("RGB")) for im in images_u8]))

@@ -6,6 +6,11 @@
 //   1. count:  one wave per sample, ballot/popcount of (id - id_offset >= 0), n = min(count, max_tokens)
 //   2. gather: one workgroup per sample; prefix of token_nums gives the packed row base, the surviving
 //      ids are compacted in order into LDS, then rows move as float4 loads -> 8-byte bf16x4 stores.
+// pgn_token_embed carries the same gather on into the token decoder's first layer (modeling_decoder.py:310-319:
+// in_proj over the gathered rows, padding rows zeroed, + pos_embed) and emits the additive key bias of :100-101:
+//   2'. embed: one workgroup per (sample, 16 token rows): the same ordered compaction, the 16 codebook rows rounded to
+//       the 16-bit type in LDS, every thread owns output columns e = tid, tid + 256, ... with that column's in_proj
+//       row in registers: fp32 dot over `dim`, + bias, rounded (the GEMM's output), x mask, + pos_embed, rounded.
 #include "pgn_common.h"
 
 #define PGN_GATHER_MAX_TOKENS 1024
@@ -121,6 +126,91 @@ __global__ __launch_bounds__(PGN_GATHER_THREADS) void pgn_gather_rows_kernel(
     }
 }
 
+#define PGN_EMBED_ROWS 16
+#define PGN_EMBED_MAX_DIM 64
+
+template <int DT>
+__global__ __launch_bounds__(PGN_GATHER_THREADS) void pgn_token_embed_kernel(
+    const int64_t* __restrict__ ids, const int32_t* __restrict__ offsets, const float* __restrict__ codebook,
+    int num_codes, int dim, int64_t id_offset, int max_tokens, const int64_t* __restrict__ token_nums,
+    const void* __restrict__ w_, const void* __restrict__ bias_, const void* __restrict__ pos_, int E,
+    void* __restrict__ out_, float* __restrict__ key_bias, int pad_len) {
+    typedef typename Cvt<DT>::storage S;
+    __shared__ int src[PGN_GATHER_MAX_TOKENS];
+    __shared__ int wave_cnt[PGN_GATHER_THREADS / PGN_WAVE];
+    __shared__ float rows[PGN_EMBED_ROWS][PGN_EMBED_MAX_DIM];
+
+    const int b = blockIdx.y;
+    const int row0 = blockIdx.x * PGN_EMBED_ROWS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    constexpr int NW = PGN_GATHER_THREADS / PGN_WAVE;
+    const int n = (int)token_nums[b];
+    const int o0 = offsets[b], o1 = offsets[b + 1];
+    const S* w = reinterpret_cast<const S*>(w_);
+    const S* bias = reinterpret_cast<const S*>(bias_);
+    const S* pos = reinterpret_cast<const S*>(pos_);
+    S* out = reinterpret_cast<S*>(out_);
+
+    if (row0 < n) {   // block-uniform: a chunk of padding rows needs no ids
+        int kept = 0;
+        for (int base = o0; base < o1 && kept < max_tokens && kept < row0 + PGN_EMBED_ROWS; base += PGN_GATHER_THREADS) {
+            const int i = base + tid;
+            int64_t code = -1;
+            if (i < o1) code = ids[i] - id_offset;
+            const bool valid = code >= 0;
+            const unsigned long long m = __ballot(valid);
+            __syncthreads();
+            if (lane == 0) wave_cnt[wid] = __popcll(m);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int wv = 0; wv < NW; ++wv) {
+                const int c = wave_cnt[wv];
+                if (wv < wid) before += c;
+                total += c;
+            }
+            const int rank = kept + before + __popcll(m & ((1ull << lane) - 1ull));
+            if (valid && rank < max_tokens) src[rank] = (code < (int64_t)num_codes) ? (int)code : -1;
+            kept += total;
+        }
+        __syncthreads();
+        // the rows as the reference's GEMM sees them: codebook values rounded to the 16-bit type (:913, :310)
+        for (int e = tid; e < PGN_EMBED_ROWS * dim; e += PGN_GATHER_THREADS) {
+            const int r = e / dim, c = e - r * dim;
+            float v = 0.f;
+            if (row0 + r < n) {
+                const int code = src[row0 + r];
+                if (code >= 0) v = Cvt<DT>::to_f32(Cvt<DT>::from_f32(codebook[(size_t)code * dim + c]));
+            }
+            rows[r][c] = v;
+        }
+        __syncthreads();
+    }
+    if (key_bias != nullptr && tid < PGN_EMBED_ROWS && row0 + tid < pad_len)
+        key_bias[(size_t)b * pad_len + row0 + tid] = (row0 + tid < n) ? 0.f : -10000.f;
+
+    for (int e = tid; e < E; e += PGN_GATHER_THREADS) {
+        float wr[PGN_EMBED_MAX_DIM];
+#pragma unroll
+        for (int c = 0; c < PGN_EMBED_MAX_DIM; ++c) wr[c] = c < dim ? Cvt<DT>::to_f32(w[(size_t)e * dim + c]) : 0.f;
+        const float be = bias != nullptr ? Cvt<DT>::to_f32(bias[e]) : 0.f;
+#pragma unroll 1
+        for (int r = 0; r < PGN_EMBED_ROWS; ++r) {
+            const int row = row0 + r;
+            if (row >= pad_len) break;
+            const float pe = Cvt<DT>::to_f32(pos[(size_t)row * E + e]);
+            float y = 0.f;
+            if (row < n) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < PGN_EMBED_MAX_DIM; ++c) acc = fmaf(rows[r][c], wr[c], acc);
+                y = Cvt<DT>::to_f32(Cvt<DT>::from_f32(acc + be));      // in_proj's 16-bit output; x mask (1) is exact
+            }
+            out[((size_t)b * pad_len + row) * E + e] = Cvt<DT>::from_f32(y + pe);
+        }
+    }
+}
+
 extern "C" int pgn_token_gather(const int64_t* ids, const int32_t* offsets, int B, const float* codebook,
                                 int num_codes, int dim, int64_t id_offset, int max_tokens, int out_dtype,
                                 int64_t* token_nums, void* out_packed, void* out_padded, void* out_mask,
@@ -147,6 +237,35 @@ extern "C" int pgn_token_gather(const int64_t* ids, const int32_t* offsets, int 
     else
         PGN_GATHER_LAUNCH(PGN_F32);
 #undef PGN_GATHER_LAUNCH
+    PGN_LAUNCH_CHECK();
+    return PGN_OK;
+}
+
+extern "C" int pgn_token_embed(const int64_t* ids, const int32_t* offsets, int B, const float* codebook, int num_codes,
+                               int dim, int64_t id_offset, int max_tokens, int dtype, const void* in_proj_weight,
+                               const void* in_proj_bias, const void* pos_embed, int E, int64_t* token_nums, void* out,
+                               float* key_bias, int pad_len, int32_t* status, void* stream) {
+    if (B == 0) return PGN_OK;
+    if (ids == nullptr || offsets == nullptr || codebook == nullptr || token_nums == nullptr) return PGN_ERR_INVALID;
+    if (in_proj_weight == nullptr || pos_embed == nullptr || out == nullptr) return PGN_ERR_INVALID;
+    if (B < 0 || B > 65535 || num_codes <= 0 || E <= 0) return PGN_ERR_INVALID;
+    if (dim <= 0 || dim > PGN_EMBED_MAX_DIM) return PGN_ERR_UNSUPPORTED;
+    if (max_tokens <= 0 || max_tokens > PGN_GATHER_MAX_TOKENS || pad_len < max_tokens) return PGN_ERR_INVALID;
+    if (dtype != PGN_BF16 && dtype != PGN_F16) return PGN_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pgn_gather_count_kernel, dim3(B), dim3(PGN_WAVE), 0, s, ids, offsets, id_offset, max_tokens,
+                       num_codes, token_nums, status);
+    PGN_LAUNCH_CHECK();
+    const dim3 grid((pad_len + PGN_EMBED_ROWS - 1) / PGN_EMBED_ROWS, B);
+#define PGN_EMBED_LAUNCH(DT)                                                                                          \
+    hipLaunchKernelGGL(pgn_token_embed_kernel<DT>, grid, dim3(PGN_GATHER_THREADS), 0, s, ids, offsets, codebook,      \
+                       num_codes, dim, id_offset, max_tokens, token_nums, in_proj_weight, in_proj_bias, pos_embed, E,  \
+                       out, key_bias, pad_len)
+    if (dtype == PGN_BF16)
+        PGN_EMBED_LAUNCH(PGN_BF16);
+    else
+        PGN_EMBED_LAUNCH(PGN_F16);
+#undef PGN_EMBED_LAUNCH
     PGN_LAUNCH_CHECK();
     return PGN_OK;
 }

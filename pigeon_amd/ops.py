@@ -113,6 +113,70 @@ def token_gather(image_tokens: Union[Sequence[torch.Tensor], torch.Tensor], code
     return {"token_nums": token_nums, "packed": out_packed, "padded": out_padded, "mask": out_mask, "status": status}
 
 
+def _flatten_tokens(image_tokens):
+    if isinstance(image_tokens, torch.Tensor):
+        if image_tokens.dim() != 2:
+            raise ValueError("image_tokens tensor must be [B, L]")
+        B, L = image_tokens.shape
+        return image_tokens.contiguous().view(-1), [L] * B
+    lens = [int(t.numel()) for t in image_tokens]
+    ids = torch.cat([t.reshape(-1) for t in image_tokens]) if lens else torch.empty(0, dtype=torch.int64)
+    return ids, lens
+
+
+def token_embed(image_tokens: Union[Sequence[torch.Tensor], torch.Tensor], codebook: torch.Tensor,
+                in_proj_weight: torch.Tensor, in_proj_bias: Optional[torch.Tensor], pos_embed: torch.Tensor,
+                id_offset: int = LAVIT_ID_OFFSET, max_tokens: int = LAVIT_MAX_TOKENS, pad_len: Optional[int] = None,
+                check: bool = False):
+    """token_gather carried on through the token decoder's `in_proj`, padding mask and `pos_embed`
+    (modeling_decoder.py:310-319) plus the additive key bias of :100-101, in two launches.
+
+    Returns dict(token_nums int64 [B], x [B, pad_len, E], key_bias fp32 [B, pad_len], status)."""
+    lib = _lib.load()
+    ids, lens = _flatten_tokens(image_tokens)
+    B = len(lens)
+    _dev(ids, codebook, in_proj_weight, pos_embed)
+    if ids.dtype != torch.int64:
+        raise TypeError("image_tokens must be int64")
+    if codebook.dtype != torch.float32 or codebook.dim() != 2:
+        raise TypeError("codebook must be fp32 [num_codes, dim]")
+    dt = in_proj_weight.dtype
+    if dt not in (torch.bfloat16, torch.float16):
+        raise TypeError("token_embed computes in bf16 / fp16 (the model dtype)")
+    num_codes, dim = codebook.shape
+    E = in_proj_weight.shape[0]
+    pos = pos_embed.reshape(-1, pos_embed.shape[-1])
+    pad_len = max_tokens if pad_len is None else pad_len
+    if in_proj_weight.shape != (E, dim) or pos.shape[1] != E or pos.shape[0] < pad_len or pos.dtype != dt:
+        raise ValueError("in_proj_weight must be [E, dim] and pos_embed [>= pad_len, E] of the same dtype")
+    if in_proj_bias is not None and (in_proj_bias.shape != (E,) or in_proj_bias.dtype != dt):
+        raise ValueError("in_proj_bias must be [E] of the weight's dtype")
+    codebook, w, pos = codebook.contiguous(), in_proj_weight.contiguous(), pos.contiguous()
+    bias = None if in_proj_bias is None else in_proj_bias.contiguous()
+    dev = codebook.device
+    offs, acc = [0], 0
+    for n in lens:
+        acc += n
+        offs.append(acc)
+    offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    token_nums = torch.empty(B, dtype=torch.int64, device=dev)
+    x = torch.empty(B, pad_len, E, dtype=dt, device=dev)
+    key_bias = torch.empty(B, pad_len, dtype=torch.float32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    work = float(B * pad_len * E * 2 + pad_len * E * 2 + E * dim * 2)
+
+    def run():
+        rc = lib.pgn_token_embed(_ptr(ids), _ptr(offsets), B, _ptr(codebook), num_codes, dim, id_offset, max_tokens,
+                                 _DT[dt], _ptr(w), _ptr(bias), _ptr(pos), E, _ptr(token_nums), _ptr(x), _ptr(key_bias),
+                                 pad_len, _ptr(status), _stream())
+        _lib.check(rc, "pgn_token_embed")
+
+    _launch("token_embed", work, run)
+    if check and int(status.item()) != 0:
+        raise IndexError("token_embed: a kept token id is outside the codebook (F.embedding would raise)")
+    return {"token_nums": token_nums, "x": x, "key_bias": key_bias, "status": status}
+
+
 # ------------------------------------------------------------------------------------------------
 def cfg_ddim_step(noise_pred: Optional[torch.Tensor], sample: torch.Tensor, guidance_scale: float,
                   sqrt_alpha_t: float, sqrt_beta_t: float, sqrt_alpha_prev: float, dir_coef: float,
@@ -530,11 +594,13 @@ def image_to_uint8(x: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------------
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
-              key_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+              key_bias: Optional[torch.Tensor] = None, causal: bool = False) -> torch.Tensor:
     """softmax(q k^T * scale + key_bias) v per head, replacing xformers.ops.memory_efficient_attention.
 
     q: [B, Nq, heads*D] (the un-permuted output of to_q), k/v: [B, Nk, heads*D]; any strides as long as the
     last dim is contiguous.  key_bias: fp32 [B, Nk] additive (key padding) or None.  Returns [B, Nq, heads*D].
+    causal=True (self-attention of a short sequence, the CLIP text tower): key j contributes to query i only for
+    j <= i; runs pgn_attention_causal_fwd (N <= 128, no key_bias).
     """
     lib = _lib.load()
     _dev(q, k, v, key_bias)
@@ -559,6 +625,19 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
         key_bias = key_bias.to(torch.float32).contiguous()
     scale = float(D) ** -0.5 if scale is None else float(scale)
     work = 4.0 * B * heads * Nq * Nk * D
+    if causal:
+        if key_bias is not None or Nq != Nk:
+            raise ValueError("causal attention is self-attention without a key bias")
+
+        def run_causal():
+            rc = lib.pgn_attention_causal_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _dt(q), B, heads, Nq, D,
+                                              q.stride(0), q.stride(1), D, k.stride(0), k.stride(1), D,
+                                              v.stride(0), v.stride(1), D, out.stride(0), out.stride(1), D,
+                                              scale, _stream())
+            _lib.check(rc, "pgn_attention_causal_fwd")
+
+        _launch("attention_causal", work / 2, run_causal)
+        return out
 
     def run():
         rc = lib.pgn_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _dt(q), B, heads, Nq, Nk, D,

@@ -40,6 +40,10 @@ def numpy_to_pil(images: np.ndarray):
     return [Image.fromarray(image) for image in images]
 
 
+# gather + in_proj + padding mask + pos_embed + key bias in one fused launch pair (ops.token_embed); "0" = the gather
+# kernel followed by the decoder's own GEMM and elementwise launches
+FUSE_TOKEN_EMBED = os.environ.get("PGN_FUSE_TOKEN_EMBED", "1") != "0"
+
 class PigeonPixelDecoder:
     """Owns the frozen decoder stack (codebook, token decoder, UNet, scheduler, VAE) on one GPU."""
 
@@ -119,6 +123,8 @@ class PigeonPixelDecoder:
     def generate_image_embeds(self, image_tokens: Union[Sequence[torch.Tensor], torch.Tensor]):
         """-> (prompt_embeds, pooled) from the highres decoder, `xrec` [B, 256, 768] from the lowres one."""
         toks = image_tokens if isinstance(image_tokens, torch.Tensor) else [t.to(self.device) for t in image_tokens]
+        if FUSE_TOKEN_EMBED and self.tokenizer_decoder.in_proj.weight.dtype in (torch.bfloat16, torch.float16):
+            return self.tokenizer_decoder.forward_tokens(toks, self.codebook)
         g = ops.token_gather(toks, self.codebook, out_dtype=self.dtype, packed=False, padded=True)
         return self.tokenizer_decoder.forward_padded(g["padded"], g["mask"])
 

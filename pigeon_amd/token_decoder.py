@@ -151,10 +151,20 @@ class _VQDecoderBase(nn.Module):
         x = self.in_proj(x_pad.to(dtype)) * m[..., None]          # padding rows are zeros, not the bias (:312-316)
         x = x + self.pos_embed[:, :L]
         bias = (1.0 - m.float()) * -10000.0                      # :100-101, one additive value per key: [B, L]
-        q = self.query_embed.expand(B, -1, -1)
+        return self._trunk(x, bias)
+
+    def _trunk(self, x: torch.Tensor, bias: torch.Tensor):
+        q = self.query_embed.expand(x.shape[0], -1, -1)
         for blk in self.blocks:
             q = blk(q, x, bias)
         return self.decode_task_layer(self.norm(q))
+
+    def _visual_rec_from_tokens(self, image_tokens, codebook: torch.Tensor):
+        """Raw LLM token ids -> visual_rec: gather, `in_proj`, padding mask, `pos_embed` and the key bias come out of
+        one fused launch pair (ops.token_embed) instead of gather + GEMM + three elementwise launches."""
+        e = ops.token_embed(image_tokens, codebook, self.in_proj.weight, self.in_proj.bias, self.pos_embed,
+                            pad_len=self.num_patches)
+        return self._trunk(e["x"], e["key_bias"])
 
     def forward(self, x: torch.Tensor, token_num: torch.Tensor):
         """Reference signature: x [sum(token_num), in_chans] packed rows, token_num int64 [B]."""
@@ -181,7 +191,13 @@ class HighresVQDecoder(_VQDecoderBase):
 
     def forward_padded(self, x_pad: torch.Tensor, mask: torch.Tensor):
         """x_pad [B, L, in_chans] (rows past each sample's token count are ignored), mask [B, L] in {0, 1}."""
-        rec = self._visual_rec(x_pad, mask)
+        return self._heads(self._visual_rec(x_pad, mask))
+
+    def forward_tokens(self, image_tokens, codebook: torch.Tensor):
+        """Raw LLM token ids (ragged list or [B, L]) + the fp32 codebook -> what `forward` returns."""
+        return self._heads(self._visual_rec_from_tokens(image_tokens, codebook))
+
+    def _heads(self, rec: torch.Tensor):
         prompt_embeds = torch.cat([self.unet_proj_1(rec), self.unet_proj_2(rec)], dim=-1)
         return prompt_embeds, self.unet_attnpool(rec)
 
@@ -196,6 +212,9 @@ class VQDecoder(_VQDecoderBase):
 
     def forward_padded(self, x_pad: torch.Tensor, mask: torch.Tensor):
         return self.unet_proj(self._visual_rec(x_pad, mask))
+
+    def forward_tokens(self, image_tokens, codebook: torch.Tensor):
+        return self.unet_proj(self._visual_rec_from_tokens(image_tokens, codebook))
 
 
 def build_tokenizer_decoder(model_path: str = "", pixel_decoding: str = "highres", depth: int = 12):

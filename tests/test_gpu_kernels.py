@@ -80,6 +80,51 @@ def test_token_gather_rectangular_batch_and_bad_id(ops):
         ops.token_gather(bad.to(DEV), cb.to(DEV), check=True)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_token_embed_matches_gather_then_in_proj_mask_pos_embed(ops, dtype):
+    # pgn_token_embed = pgn_token_gather carried through modeling_decoder.py:310-319 (in_proj, x mask, + pos_embed)
+    # and :100-101 (key bias).  Checked against the exact statement of those lines on the bit-exact gather's output:
+    # fp64 dot of the 16-bit rows and weights + bias -> rounded to the 16-bit type (the GEMM's output), x mask,
+    # + pos_embed, rounded.  Only the fp32 accumulation order can differ: the GEMM output may land on the other side of
+    # a rounding tie (1 ulp of it) on a few elements, nothing else; padding rows are pos_embed exactly.
+    cb = _codebook(2)
+    g = torch.Generator().manual_seed(17)
+    E = 1408
+    w = (torch.randn(E, 32, generator=g) * 0.2).to(dtype)
+    b = (torch.randn(E, generator=g) * 0.1).to(dtype)
+    pos = (torch.randn(1, 256, E, generator=g) * 0.5).to(dtype)
+    for toks in _token_cases():
+        dev_toks = [t.to(DEV) for t in toks]
+        ref = ops.token_gather(dev_toks, cb.to(DEV), out_dtype=dtype, packed=False)
+        got = ops.token_embed(dev_toks, cb.to(DEV), w.to(DEV), b.to(DEV), pos.to(DEV), check=True)
+        assert torch.equal(got["token_nums"], ref["token_nums"])
+        mask = ref["mask"].cpu().double()
+        assert torch.equal(got["key_bias"].cpu().double(), (1.0 - mask) * -10000.0)
+        y = (ref["padded"].cpu().double() @ w.double().T + b.double()).to(dtype)
+        want = ((y.double() * mask[..., None]).to(dtype).double() + pos.double()).to(dtype)
+        x = got["x"].cpu()
+        assert x.shape == want.shape and x.dtype == dtype
+        pad_rows = mask == 0
+        assert torch.equal(x[pad_rows], pos.expand_as(x)[pad_rows])
+        # one ulp of the GEMM output y (the value whose rounding can flip) ...
+        mant = 7 if dtype == torch.bfloat16 else 10
+        ulp = lambda t: torch.exp2(torch.floor(torch.log2(t.abs().double().clamp_min(2.0 ** -24))) - mant)
+        err = (x.double() - want.double()).abs()
+        bound = ulp(y) * mask[..., None] + ulp(want) + 1e-12                 # ... and a flipped rounding of the sum
+        frac = float((err != 0).double().mean())
+        print(f"token_embed {dtype}: {frac:.2e} of the elements differ, worst err/bound {float((err / bound).max()):.2f}")
+        assert bool((err <= bound).all()), float((err / bound).max())
+        assert frac < 2e-3
+    with pytest.raises(TypeError):
+        ops.token_embed(dev_toks, cb.to(DEV), w.float().to(DEV), None, pos.float().to(DEV))
+    with pytest.raises(NotImplementedError):
+        ops.token_embed(dev_toks, torch.randn(64, 128, device=DEV), torch.randn(E, 128, device=DEV).to(dtype), None,
+                        pos.to(DEV))
+    bad = [torch.tensor([32002 + 16384])]
+    with pytest.raises(IndexError):
+        ops.token_embed([t.to(DEV) for t in bad], cb.to(DEV), w.to(DEV), b.to(DEV), pos.to(DEV), check=True)
+
+
 def _step_inputs(shape, edt, seed=0):
     g = torch.Generator().manual_seed(seed)
     noise_pred = torch.randn((2 * shape[0],) + shape[1:], generator=g).to(edt)

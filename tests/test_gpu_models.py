@@ -2,11 +2,12 @@
 identical synthetic weights, tokens and explicit noise.  Product path = pigeon_amd modules
 calling the HIP kernels through the C ABI; oracle = oracle.models_ref / pipeline_ref on the CPU.
 
-Tolerances (stated per test) are SELF-CALIBRATING: the oracle is run twice on the CPU, in fp32 (the reference
-arithmetic) and with the reference's own bf16-autocast rounding policy.  Two bf16 evaluations of a deep network
-decorrelate at the bf16 noise floor (different GEMM accumulation orders flip roundings, which then propagate), so the
-meaningful statement is: the HIP path is as close to the fp32 reference as the reference's bf16 path is -
-    relL2(hip, fp32) <= 1.5 * relL2(oracle_bf16, fp32) + 0.003        and below an absolute cap given per test."""
+Tolerances are FIXED constants, stated per test: relative L2 of the HIP bf16 result against the fp32 oracle (the
+reference arithmetic on the unrounded synthetic weights, so the figure includes the weights' bf16 rounding), with the value measured on MI355X beside each bar (bar =
+measured x 1.35-1.45).  Two bf16 evaluations of a deep network decorrelate at the bf16 noise floor (different GEMM
+accumulation orders flip roundings, which then propagate), so the oracle's own bf16-autocast evaluation is printed next
+to it for scale - the HIP path sits within 10 % of that evaluation's distance to fp32 in every test - but it no longer
+sets the bar.  The same modules at real SDXL widths and in fp16 (8x lower floor): tests/test_gpu_widths.py."""
 import numpy as np
 import pytest
 import torch
@@ -25,11 +26,11 @@ SCHED = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", 
              steps_offset=1, clip_sample=False, set_alpha_to_one=False, timestep_spacing="leading")
 
 
-def _calibrated(got, want_bf16, want_fp32, cap, what=""):
+def _within(got, want_bf16, want_fp32, bar, what=""):
     e_hip = _rel(got, want_fp32)[1]
     e_ref = _rel(want_bf16, want_fp32)[1]
-    print(f"{what} relL2 hip-vs-fp32 {e_hip:.4f}  oracle_bf16-vs-fp32 {e_ref:.4f}  hip-vs-oracle_bf16 {_rel(got, want_bf16)[1]:.4f}")
-    assert e_hip <= 1.5 * e_ref + 0.003 and e_hip < cap, (what, e_hip, e_ref)
+    print(f"{what} relL2 hip-vs-fp32 {e_hip:.4f} (bar {bar})  oracle_bf16-vs-fp32 {e_ref:.4f}  hip-vs-oracle_bf16 {_rel(got, want_bf16)[1]:.4f}")
+    assert e_hip < bar, (what, e_hip, bar, e_ref)
 
 
 def _rel(got, want):
@@ -78,8 +79,8 @@ def test_token_decoder_gpu_matches_oracle(stack):
     assert pe.shape == (4, 256, 2048) and pooled.shape == (4, 1280) and pe.dtype == torch.bfloat16
     emb32, _ = ops_ref.token_gather_ref(tokens, stack["codebook"], torch.float32)
     want32, want_pooled32 = models_ref.token_decoder_forward(Policy(torch.float32), stack["dec_sd32"], emb32, nums)
-    _calibrated(pe, want_pe, want32, 0.03, "token decoder prompt_embeds")      # cap: 3 % of the output L2 norm
-    _calibrated(pooled, want_pooled, want_pooled32, 0.03, "token decoder pooled")
+    _within(pe, want_pe, want32, 0.014, "token decoder prompt_embeds")      # measured 0.0102
+    _within(pooled, want_pooled, want_pooled32, 0.010, "token decoder pooled")     # measured 0.0069
 
 
 def _golden_rel(got, want):
@@ -108,7 +109,8 @@ def test_product_token_decoders_match_the_reference_golden_vectors(golden_dir, d
     with torch.no_grad():
         total = int(out["token_nums"].sum())
         for what, (prompt, pooled) in (("padded", m.forward_padded(out["padded"], out["mask"])),
-                                       ("packed", m(out["packed"][:total], out["token_nums"]))):
+                                       ("packed", m(out["packed"][:total], out["token_nums"])),
+                                       ("fused token embed", m.forward_tokens(tokens, codebook))):
             e1 = _golden_rel(prompt[:, rows].float().cpu(), g["prompt_embeds_rows"])
             e2 = _golden_rel(pooled.float().cpu(), g["pooled"])
             print(f"HighresVQDecoder {what} {dt}: relL2 vs reference golden {e1:.5f} / pooled {e2:.5f}")
@@ -125,6 +127,10 @@ def test_product_token_decoders_match_the_reference_golden_vectors(golden_dir, d
     e = _golden_rel(xrec[:, rows].float().cpu(), g["xrec_rows"])
     print(f"VQDecoder {dt}: relL2 vs reference golden {e:.5f}")
     assert xrec.shape == (4, 256, 768) and e < bar
+    with torch.no_grad():
+        e = _golden_rel(m.forward_tokens(tokens, codebook)[:, rows].float().cpu(), g["xrec_rows"])
+    print(f"VQDecoder fused token embed {dt}: relL2 vs reference golden {e:.5f}")
+    assert e < bar
 
 
 def _unet_inputs(B, h, w, seed=0):
@@ -148,7 +154,7 @@ def test_unet_forward_matches_oracle(stack, hw):
                                    ctx, {"text_embeds": pooled, "time_ids": ids})
     want32 = models_ref.unet_forward(Policy(torch.float32), stack["unet_sd32"], stack["unet_cfg"], x, torch.tensor(961),
                                      ctx.float(), {"text_embeds": pooled.float(), "time_ids": ids.float()})
-    _calibrated(got, want, want32, 0.04, f"unet {hw}")    # cap: 4 % of the eps L2 norm (16 resnets + 12 transformer blocks)
+    _within(got, want, want32, 0.026, f"unet {hw}")    # measured 0.0169 / 0.0184 (16 resnets + 12 transformer blocks)
 
 
 def test_unet_key_padding_mask_path(stack):
@@ -166,7 +172,7 @@ def test_unet_key_padding_mask_path(stack):
     want32 = models_ref.unet_forward(Policy(torch.float32), stack["unet_sd32"], stack["unet_cfg"], x, torch.tensor(500),
                                      ctx.float(), {"text_embeds": pooled.float(), "time_ids": ids.float()},
                                      encoder_attention_mask=mask)
-    _calibrated(got, want, want32, 0.04, "unet key-padding mask")
+    _within(got, want, want32, 0.026, "unet key-padding mask")    # measured 0.0193
     unmasked = unet(x.to(DEV), 500, encoder_hidden_states=ctx.to(DEV), added_cond_kwargs=kw).sample
     assert _rel(unmasked, want32)[1] > 2 * _rel(got, want32)[1]   # the mask matters
 
@@ -235,7 +241,7 @@ def test_vae_decode_matches_oracle(stack):
     assert got.shape == (2, 3, 32, 32)
     want32 = models_ref.vae_decode(Policy(torch.float32), {k: v.float() for k, v in stack["vae_sd"].items()},
                                    stack["vae_cfg"], z.to(torch.bfloat16).float() / 0.13025)
-    _calibrated(got, want, want32, 0.03, "vae decode")
+    _within(got, want, want32, 0.010, "vae decode")    # measured 0.0068
     u8 = pipe.decode_latents(z.to(DEV), "uint8").cpu().numpy()
     pil = pipe.decode_latents(z.to(DEV), "pil")
     assert u8.shape == (2, 32, 32, 3) and u8.dtype == np.uint8 and len(pil) == 2
@@ -355,9 +361,9 @@ def test_generate_image_per_step_latents_match_oracle(stack):
                                             stack["unet_sd32"], stack["unet_cfg"], pipeline_ref.DDIMRef(**SCHED), noise,
                                             num_return_images=k, width=W, height=H, num_inference_steps=steps,
                                             guidance_scale=7.0)
-    # per-step latents (cap 8 % of the latent L2 norm after 4 guided steps: eps noise x guidance 7 accumulates)
+    # per-step latents (eps noise x guidance 7 accumulates over the 4 guided steps)
     for i, (a, b, c) in enumerate(zip(got_steps, ref["latents_per_step"], ref32["latents_per_step"])):
-        _calibrated(a, b, c, 0.08, f"latents after step {i}")
+        _within(a, b, c, 0.043, f"latents after step {i}")    # measured 0.0304-0.0308
     assert images.shape == (2 * k, H // 4, W // 4, 3)   # tiny VAE upsamples x2 once (16x20 -> 32x40)
     d = np.abs(images.cpu().numpy().astype(int) - ref["images"].astype(int))
     assert d.mean() < 3.0 and np.percentile(d, 99) <= 12, (d.mean(), d.max())
@@ -610,10 +616,10 @@ def test_pixel_decoding_origin_per_step_latents_match_oracle(lowres_stack):
                                                    st["unet_sd32"], st["unet_cfg"], pipeline_ref.DDIMRef(**SD15_SCHED),
                                                    st["uncond"], noise, **kw)
     assert xrec.shape == (3, 256, 768) and xrec.dtype == torch.bfloat16
-    _calibrated(xrec, ref["xrec"], ref32["xrec"], 0.03, "lowres xrec")
+    _within(xrec, ref["xrec"], ref32["xrec"], 0.014, "lowres xrec")    # measured 0.0101
     assert len(got_steps) == steps
     for i, (a, b, c) in enumerate(zip(got_steps, ref["latents_per_step"], ref32["latents_per_step"])):
-        _calibrated(a, b, c, 0.08, f"lowres latents after step {i}")
+        _within(a, b, c, 0.028, f"lowres latents after step {i}")    # measured 0.0196-0.0206
     d = np.abs(images.cpu().numpy().astype(int) - ref["images"].astype(int))
     assert images.shape == (3, H // 4, W // 4, 3) and d.mean() < 3.0 and np.percentile(d, 99) <= 12, (d.mean(), d.max())
 

@@ -152,7 +152,7 @@ def test_vision_tower_and_scorer_on_gpu_match_oracle():
     rel = lambda a, b: ((a.float().cpu() - b.float()).norm() / b.float().norm()).item()
     e_hip, e_ref = rel(feats, want32), rel(want16, want32)
     print(f"clip tower relL2 hip-vs-fp32 {e_hip:.4f} oracle_bf16-vs-fp32 {e_ref:.4f}")
-    assert feats.shape == (5, 128) and e_hip <= 1.5 * e_ref + 0.003 and e_hip < 0.03
+    assert feats.shape == (5, 128) and e_hip < 0.010          # fixed bar; measured 0.0069 (the oracle's own bf16: 0.0070)
     scores = scorer.score(images, txt, hist, resize_hw=(256, 256)).cpu()
     want_t, want_h = scoring_ref.clip_scores_ref(want32, txt, hist)
     assert scores.shape == (5, 2)
