@@ -20,7 +20,8 @@ def check(var):
     worst = 0.0
     for B, H, Nq, Nk, has_bias in ((2, 10, 1024, 1024, False), (1, 4, 4096, 4096, False), (2, 20, 1024, 256, False), (2, 5, 988, 988, False),
                                    (1, 2, 3952, 3952, False), (2, 4, 300, 77, True), (3, 2, 1, 1, False), (2, 3, 257, 65, False),
-                                   (2, 8, 1024, 256, True), (2, 2, 130, 128, False), (2, 2, 64, 129, True), (1, 1, 33, 192, False)):
+                                   (2, 8, 1024, 256, True), (2, 2, 130, 128, False), (2, 2, 64, 129, True), (1, 1, 33, 192, False),
+                                   (9, 20, 1024, 1024, False), (40, 16, 256, 1280, False)):
         g = torch.Generator().manual_seed(Nq + Nk)
         C = H * 64
         q = (torch.randn(B, Nq, C, generator=g) * 1.5).bfloat16(); k = (torch.randn(B, Nk, C, generator=g) * 1.5).bfloat16()

@@ -367,6 +367,35 @@ def test_attention_rescale_branch_of_the_64_row_kernel(ops):
     assert (want[:, 17] - v[:, 1500].float()).abs().max().item() < 0.25
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,dtype", [(9, 20, 1024, 1024, torch.bfloat16), (5, 16, 2048, 1024, torch.float16),
+                                             (20, 16, 512, 1280, torch.bfloat16)],
+                         ids=["720items", "640items_fp16", "640items_short"])
+def test_attention_64_row_kernel_more_workgroups_than_resident_slots(ops, B, H, Nq, Nk, dtype):
+    # More (batch, head, 256-row block) workgroups than the 512 that are resident at once (two per CU): every output
+    # row against the fp32 oracle (per batch, to bound host memory), strided q / k / v views of one fused projection,
+    # a late score spike in one batch.  (Written for a persistent form of the kernel that was measured and not kept,
+    # DESIGN.md section 4; the shapes stay as coverage of multi-round launches.)
+    C = H * 64
+    g = torch.Generator().manual_seed(B + Nq)
+    if Nq == Nk:
+        qkv = (torch.randn(B, Nq, 3 * C, generator=g) * 1.3).to(dtype)
+        qkv[B - 1, Nk - 40, C:2 * C] = qkv[B - 1, 5, 0:C] * 3.0
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        dq = qkv.to(DEV)
+        got = ops.attention(dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:], H)
+    else:
+        q = (torch.randn(B, Nq, C, generator=g) * 1.3).to(dtype)
+        k = (torch.randn(B, Nk, C, generator=g) * 1.3).to(dtype)
+        v = torch.randn(B, Nk, C, generator=g).to(dtype)
+        got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H)
+    got = got.cpu().float()
+    worst = 0.0
+    for b in range(B):
+        want = ops_ref.attention_ref(q[b:b + 1], k[b:b + 1], v[b:b + 1], H).float()
+        worst = max(worst, (got[b:b + 1] - want).abs().max().item() / (2.0 ** -7 * max(1.0, want.abs().max().item())))
+    assert worst < 1.0, worst
+
+
 def test_attention_full_size_properties(ops):
     # BASELINE config-2 level-1 self-attention (B' = 32, 10 heads, N = 4096): checked through properties.
     B, H, N = 32, 10, 4096
