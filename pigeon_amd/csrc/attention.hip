@@ -662,7 +662,11 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     // SDXL shape (scripts/bench_kernels.py): 4 waves beat the 8-wave 256-row geometry by 4 % (self, N 4096) to
     // 30 % (cross, Nk 256); the 8-wave form is compiled into the measurement build only (PGN_TUNING_HOOKS).
     int nw = 4;
-    bool w64 = D == 64 && key_bias == nullptr && Nk >= 1024 && Nq >= 512;
+    // ... and only with at least 1024 of its 256-row workgroups (two rounds of the 512 resident ones): below that the
+    // 128-row workgroups of the 32-row kernel fill the chip better (batch 1 / 2 / 4 runs, N = 4096: 716 vs 616
+    // TFLOP/s at 320 workgroups, 835 vs 778 at 640, 871 vs 953 at 1280; profiles/r02_attention_small_batches.txt).
+    bool w64 = D == 64 && key_bias == nullptr && Nk >= 1024 && Nq >= 512 &&
+               (long long)B * H * ((Nq + 255) / 256) >= 1024;
     if (g_attn_variant == 16 && D == 64) nw = 8;
     if (g_attn_variant == 1 || nw == 8) w64 = false;
     if (g_attn_variant == 3) w64 = D == 64 && key_bias == nullptr;

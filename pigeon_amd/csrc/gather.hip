@@ -175,10 +175,12 @@ __global__ __launch_bounds__(PGN_GATHER_THREADS) void pgn_token_embed_kernel(
         }
         __syncthreads();
         // the rows as the reference's GEMM sees them: codebook values rounded to the 16-bit type (:913, :310)
-        for (int e = tid; e < PGN_EMBED_ROWS * dim; e += PGN_GATHER_THREADS) {
-            const int r = e / dim, c = e - r * dim;
+        // (all PGN_EMBED_MAX_DIM columns are written: the dot product below runs over the full width against zero
+        // weights, and 0 x LDS garbage would be NaN whenever the garbage is)
+        for (int e = tid; e < PGN_EMBED_ROWS * PGN_EMBED_MAX_DIM; e += PGN_GATHER_THREADS) {
+            const int r = e / PGN_EMBED_MAX_DIM, c = e - r * PGN_EMBED_MAX_DIM;
             float v = 0.f;
-            if (row0 + r < n) {
+            if (c < dim && row0 + r < n) {
                 const int code = src[row0 + r];
                 if (code >= 0) v = Cvt<DT>::to_f32(Cvt<DT>::from_f32(codebook[(size_t)code * dim + c]));
             }

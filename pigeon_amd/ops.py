@@ -650,7 +650,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     # bias and with >= 16 key tiles goes to the 64-rows-per-wave LDS-DMA kernel
     if D != 64:
         kind = f"attention_d{D}"
-    elif key_bias is None and Nk >= 1024 and Nq >= 512:
+    elif key_bias is None and Nk >= 1024 and Nq >= 512 and B * heads * ((Nq + 255) // 256) >= 1024:
         kind = "attention_w64"
     else:
         kind = "attention"

@@ -93,6 +93,11 @@ def test_token_embed_matches_gather_then_in_proj_mask_pos_embed(ops, dtype):
     w = (torch.randn(E, 32, generator=g) * 0.2).to(dtype)
     b = (torch.randn(E, generator=g) * 0.1).to(dtype)
     pos = (torch.randn(1, 256, E, generator=g) * 0.5).to(dtype)
+    # LDS is not cleared between kernels: leave NaN bit patterns in every CU's LDS (an attention launch over NaN
+    # inputs stages them as K / V tiles) so that a kernel reading LDS it has not written shows up as NaN output
+    # (regression: the dot product ran over 64 columns of which only `dim` = 32 had been filled)
+    nan = torch.full((64, 512, 640), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.attention(nan, nan, nan, 10)
     for toks in _token_cases():
         dev_toks = [t.to(DEV) for t in toks]
         ref = ops.token_gather(dev_toks, cb.to(DEV), out_dtype=dtype, packed=False)
@@ -103,7 +108,7 @@ def test_token_embed_matches_gather_then_in_proj_mask_pos_embed(ops, dtype):
         y = (ref["padded"].cpu().double() @ w.double().T + b.double()).to(dtype)
         want = ((y.double() * mask[..., None]).to(dtype).double() + pos.double()).to(dtype)
         x = got["x"].cpu()
-        assert x.shape == want.shape and x.dtype == dtype
+        assert x.shape == want.shape and x.dtype == dtype and bool(torch.isfinite(x.float()).all())
         pad_rows = mask == 0
         assert torch.equal(x[pad_rows], pos.expand_as(x)[pad_rows])
         # one ulp of the GEMM output y (the value whose rounding can flip) ...
@@ -299,11 +304,24 @@ ATTN_CASES = [
     (3, 2, 1, 1, torch.bfloat16, False),
     (2, 3, 257, 65, torch.float16, False),
     (2, 8, 1024, 256, torch.bfloat16, True),      # lowres-style encoder_attention_mask
-    # the 64-rows-per-wave LDS-DMA kernel (head dim 64, no bias, Nk >= 1024, Nq >= 512): ragged on both sides, fp16
-    (1, 2, 1000, 1100, torch.bfloat16, False),
-    (1, 3, 1024, 1536, torch.float16, False),
-    (2, 2, 520, 1025, torch.bfloat16, False),     # one key in the last tile, 8 rows in the last workgroup
+    # the 64-rows-per-wave LDS-DMA kernel (head dim 64, no bias, Nk >= 1024, Nq >= 512 and at least 1024 of its
+    # 256-row workgroups): ragged on both sides, fp16
+    (16, 16, 1000, 1100, torch.bfloat16, False),
+    (8, 32, 1024, 1536, torch.float16, False),
+    (22, 16, 520, 1025, torch.bfloat16, False),   # one key in the last tile, 8 rows in the last workgroup
+    (1, 2, 1000, 1100, torch.bfloat16, False),    # the same shapes below the workgroup threshold: the 32-row kernel
+    (2, 2, 520, 1025, torch.bfloat16, False),
 ]
+
+
+def _attn_err_over_bar(got, q, k, v, H, bias=None):
+    """worst |got - oracle| / (2^-7 max(1, max|oracle|)) with the fp32 oracle evaluated per batch (bounded host memory)"""
+    worst = 0.0
+    for b in range(q.shape[0]):
+        want = ops_ref.attention_ref(q[b:b + 1], k[b:b + 1], v[b:b + 1], H, None,
+                                     None if bias is None else bias[b:b + 1]).float()
+        worst = max(worst, (got[b:b + 1] - want).abs().max().item() / (2.0 ** -7 * max(1.0, want.abs().max().item())))
+    return worst
 
 
 def _attn_inputs(B, H, Nq, Nk, dtype, seed):
@@ -324,13 +342,11 @@ def test_attention_matches_oracle(ops, case):
         keep = torch.randint(1, Nk + 1, (B,), generator=torch.Generator().manual_seed(1))
         mask = (torch.arange(Nk)[None, :] < keep[:, None]).float()
         bias = (1.0 - mask) * -10000.0  # modeling_decoder.py:100-101 / diffusers encoder_attention_mask
-    want = ops_ref.attention_ref(q, k, v, H, None, bias).float()
     got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H, None, None if bias is None else bias.to(DEV)).cpu().float()
-    err = (got - want).abs().max().item()
     # tolerance: P is rounded to bf16 before P.V (as in xformers' kernel) and the output once more:
-    # 2^-8 relative on O(1) values
-    tol = 2.0 ** -7 * max(1.0, want.abs().max().item())
-    assert err < tol, f"max abs err {err} (tol {tol})"
+    # 2^-8 relative on O(1) values -> bar 2^-7 max(1, max|want|)
+    err = _attn_err_over_bar(got, q, k, v, H, bias)
+    assert err < 1.0, f"max abs err / bar {err}"
 
 
 def test_attention_strided_inputs_and_rescale_branch(ops):
@@ -352,26 +368,26 @@ def test_attention_rescale_branch_of_the_64_row_kernel(ops):
     # same late-spike construction on a shape the 64-rows-per-wave kernel takes (Nk >= 1024): the deferred softmax
     # reference (raised only when a row maximum outgrows it by 2^8) must be raised in a late tile for SOME rows of a
     # block (key 1500 aligned with queries 17 and 300) and left alone for moderate growth (key 700, query 40)
-    B, H, N = 2, 3, 1600
+    B, H, N = 10, 15, 1600                  # 1050 workgroups of 256 rows: the 64-row kernel's side of the heuristic
     C = H * 64
     g = torch.Generator().manual_seed(11)
     qkv = torch.randn(B, N, 3 * C, generator=g).to(torch.bfloat16)
     qkv[:, 1500, C:2 * C] = (qkv[:, 17, 0:C].float() * 2.5 + qkv[:, 300, 0:C].float() * 2.5).to(torch.bfloat16)
     qkv[:, 700, C:2 * C] = qkv[:, 40, 0:C] * 0.5
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    want = ops_ref.attention_ref(q, k, v, H).float()
     dq = qkv.to(DEV)
     got = ops.attention(dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:], H).cpu().float()
-    assert (got - want).abs().max().item() < 2.0 ** -7 * max(1.0, want.abs().max().item())
+    assert _attn_err_over_bar(got, q, k, v, H) < 1.0
     # the spike really dominates rows 17 and 300 (their output is close to V row 1500), i.e. the branch was exercised
-    assert (want[:, 17] - v[:, 1500].float()).abs().max().item() < 0.25
+    want0 = ops_ref.attention_ref(q[:1], k[:1], v[:1], H).float()
+    assert (want0[:, 17] - v[:1, 1500].float()).abs().max().item() < 0.25
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk,dtype", [(9, 20, 1024, 1024, torch.bfloat16), (5, 16, 2048, 1024, torch.float16),
-                                             (20, 16, 512, 1280, torch.bfloat16)],
-                         ids=["720items", "640items_fp16", "640items_short"])
+@pytest.mark.parametrize("B,H,Nq,Nk,dtype", [(13, 20, 1024, 1024, torch.bfloat16), (8, 16, 2048, 1024, torch.float16),
+                                             (32, 16, 512, 1280, torch.bfloat16)],
+                         ids=["1040wgs", "1024wgs_fp16", "1024wgs_short"])
 def test_attention_64_row_kernel_more_workgroups_than_resident_slots(ops, B, H, Nq, Nk, dtype):
-    # More (batch, head, 256-row block) workgroups than the 512 that are resident at once (two per CU): every output
+    # At least two rounds of the 512 resident (batch, head, 256-row block) workgroups (two per CU): every output
     # row against the fp32 oracle (per batch, to bound host memory), strided q / k / v views of one fused projection,
     # a late score spike in one batch.  (Written for a persistent form of the kernel that was measured and not kept,
     # DESIGN.md section 4; the shapes stay as coverage of multi-round launches.)
@@ -388,11 +404,7 @@ def test_attention_64_row_kernel_more_workgroups_than_resident_slots(ops, B, H, 
         k = (torch.randn(B, Nk, C, generator=g) * 1.3).to(dtype)
         v = torch.randn(B, Nk, C, generator=g).to(dtype)
         got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H)
-    got = got.cpu().float()
-    worst = 0.0
-    for b in range(B):
-        want = ops_ref.attention_ref(q[b:b + 1], k[b:b + 1], v[b:b + 1], H).float()
-        worst = max(worst, (got[b:b + 1] - want).abs().max().item() / (2.0 ** -7 * max(1.0, want.abs().max().item())))
+    worst = _attn_err_over_bar(got.cpu().float(), q, k, v, H)
     assert worst < 1.0, worst
 
 
