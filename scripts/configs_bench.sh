@@ -8,11 +8,14 @@ run() {  # tag, bench args...
   python3 - <<PY
 import json
 d=json.loads(open("gpurun_out/cfg_$tag.json").read().strip().splitlines()[-1])
-print("$tag", "images/s", round(d["value"],4), "ms/step", round(d["ms_per_step"],1), "loop-only images/s", round(d["loop_only"]["images_per_sec_per_gpu"],4))
+print("$tag", "images/s", round(d["value"],4), "ms/step", round(d["ms_per_step"],1), "loop-only images/s", (round(d["loop_only"]["images_per_sec_per_gpu"],4) if (d.get("loop_only") or {}).get("images_per_sec_per_gpu") else None))
 PY
 }
 run b1 --batch 1 --steps 3 &&
+run b2 --batch 2 --steps 3 &&
 run b4 --batch 4 --steps 2 &&
-run cfg3_share --batch 8 --height 1216 --width 832 --denoise-steps 50 --steps 1 &&
-run cfg4_share --batch 16 --num-return-images 8 --steps 1 &&
-run b16 --steps 2
+run b1_graph --batch 1 --steps 3 --hip-graph &&
+run config2_share --config 2 --steps 1 &&
+run config3_share --config 3 --steps 1 &&
+run config4 --config 4 --steps 2 &&
+run config1 --steps 2
