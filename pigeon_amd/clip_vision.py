@@ -182,6 +182,8 @@ class CLIPScorer:
         """eval_utils.py:126 (`self.model.encode_text(self.tokenizer(texts))`) -> [len(texts), output_dim]."""
         if self.text is None or self.tokenizer is None:
             raise RuntimeError("CLIPScorer was built without a text tower / tokenizer: pass text_features instead")
+        if len(texts) == 0:
+            return torch.empty(0, self.text.config["output_dim"], device=self.device, dtype=self.text.dtype)
         feats = []
         for i in range(0, len(texts), self.batch_size):
             tokens = self.tokenizer(list(texts[i:i + self.batch_size])).to(self.device)

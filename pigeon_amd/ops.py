@@ -135,6 +135,8 @@ def token_embed(image_tokens: Union[Sequence[torch.Tensor], torch.Tensor], codeb
     lib = _lib.load()
     ids, lens = _flatten_tokens(image_tokens)
     B = len(lens)
+    if B == 0:
+        raise ValueError("token_embed needs at least one token sequence")
     _dev(ids, codebook, in_proj_weight, pos_embed)
     if ids.dtype != torch.int64:
         raise TypeError("image_tokens must be int64")
