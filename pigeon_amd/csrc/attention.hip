@@ -34,7 +34,6 @@ constexpr float ATT_DEFER_LOG2 = 8.0f;
 // a workgroup = NWAVES wave64, 32 query rows each: NWAVES = 8 (256 rows, 2 waves per SIMD) for long key sequences,
 // NWAVES = 4 (128 rows, several workgroups per CU) when the key loop is short and prologue latency dominates
 
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;

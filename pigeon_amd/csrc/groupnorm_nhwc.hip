@@ -93,17 +93,24 @@ __device__ __forceinline__ float nh_silu(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-template <int DT>
+// HAS_ADD (the per-(sample, channel) addend of ResnetBlock2D's norm2) and, in the apply kernel, ACT are compile-time:
+// as run-time flags they were if-converted into ~110 v_cndmask per loop body.  The per-element arithmetic is written on
+// float pairs so that it compiles to packed fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma: two elements per issue
+// slot); the operations and their order are unchanged, results are bit-identical to the scalar form.
+template <int DT, bool HAS_ADD>
 __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArgs a) {
     extern __shared__ float2 sh[];   // [R][C]
     const int n = blockIdx.x / a.S, sc = blockIdx.x % a.S;
     const int t = threadIdx.x;
     const int r = t / a.C8, cc = t - r * a.C8;
     const bool active = r < a.R;
-    const bool has_add = a.addnc != nullptr;
-    float tadd[8], piv[8], s[8], q[8];
+    constexpr bool has_add = HAS_ADD;
+    float tadd[8], piv[8];
+    f32x2_t s2[4], q2[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { tadd[j] = 0.f; piv[j] = 0.f; s[j] = 0.f; q[j] = 0.f; }
+    for (int j = 0; j < 8; ++j) { tadd[j] = 0.f; piv[j] = 0.f; }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { s2[p] = f32x2_t{0.f, 0.f}; q2[p] = f32x2_t{0.f, 0.f}; }
     if (active) {
         if (has_add) nh_param8(a.addnc, a.add_dt, (size_t)n * a.C + cc * 8, 0.f, tadd);
         int pitch;
@@ -112,12 +119,15 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArg
         const int row1 = min(a.HW, (sc + 1) * a.rows);
         auto accum = [&](const u16x8_t& v) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float f = Cvt<DT>::to_f32(v[j]);
-                if (has_add) f = Cvt<DT>::to_f32(Cvt<DT>::from_f32(f + tadd[j]));
-                const float d = f - piv[j];
-                s[j] += d;
-                q[j] += d * d;
+            for (int p = 0; p < 4; ++p) {
+                f32x2_t f = {Cvt<DT>::to_f32(v[2 * p]), Cvt<DT>::to_f32(v[2 * p + 1])};
+                if constexpr (HAS_ADD) {
+                    f += f32x2_t{tadd[2 * p], tadd[2 * p + 1]};
+                    f = f32x2_t{Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[0])), Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[1]))};
+                }
+                const f32x2_t d = f - f32x2_t{piv[2 * p], piv[2 * p + 1]};
+                s2[p] += d;
+                q2[p] += d * d;
             }
         };
         int row = sc * a.rows + r;
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArg
         }
         for (; row < row1; row += a.R) accum(*reinterpret_cast<const u16x8_t*>(xp + (size_t)row * pitch));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sh[(size_t)r * a.C + cc * 8 + j] = make_float2(s[j], q[j]);
+        for (int j = 0; j < 8; ++j) sh[(size_t)r * a.C + cc * 8 + j] = make_float2(s2[j >> 1][j & 1], q2[j >> 1][j & 1]);
     }
     __syncthreads();
     for (int c = t; c < a.C; c += blockDim.x) {
@@ -202,16 +212,15 @@ __global__ __launch_bounds__(NH_FIN_THREADS) void pgn_gn_nhwc_finalize_kernel(Nh
     if (t == 0) a.stats[(size_t)n * a.G + g] = make_float2(mean, 1.0f / sqrtf(var + a.eps));
 }
 
-template <int DT>
+template <int DT, bool HAS_ADD, bool ACT>
 __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArgs a) {
     const int n = blockIdx.x / a.S, sc = blockIdx.x % a.S;
     const int t = threadIdx.x;
     const int r = t / a.C8, cc = t - r * a.C8;
     if (r >= a.R) return;
     const size_t img = (size_t)n * a.HW * a.C;
-    const bool has_add = a.addnc != nullptr;
     float tadd[8], mean[8], ga[8], be[8];
-    nh_param8(has_add ? a.addnc : nullptr, a.add_dt, (size_t)n * a.C + cc * 8, 0.f, tadd);
+    nh_param8(HAS_ADD ? a.addnc : nullptr, a.add_dt, (size_t)n * a.C + cc * 8, 0.f, tadd);
     nh_param8(a.gamma, a.adt, (size_t)cc * 8, 1.f, ga);
     nh_param8(a.beta, a.adt, (size_t)cc * 8, 0.f, be);
 #pragma unroll
@@ -227,11 +236,21 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArg
     auto apply = [&](const u16x8_t& v, size_t e) {
         u16x8_t o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float f = Cvt<DT>::to_f32(v[j]);
-            if (has_add) f = Cvt<DT>::to_f32(Cvt<DT>::from_f32(f + tadd[j]));
-            const float w = (f - mean[j]) * ga[j] + be[j];
-            o[j] = Cvt<DT>::from_f32(a.act ? nh_silu(w) : w);
+        for (int p = 0; p < 4; ++p) {
+            f32x2_t f = {Cvt<DT>::to_f32(v[2 * p]), Cvt<DT>::to_f32(v[2 * p + 1])};
+            if constexpr (HAS_ADD) {
+                f += f32x2_t{tadd[2 * p], tadd[2 * p + 1]};
+                f = f32x2_t{Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[0])), Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[1]))};
+            }
+            f32x2_t w = (f - f32x2_t{mean[2 * p], mean[2 * p + 1]}) * f32x2_t{ga[2 * p], ga[2 * p + 1]} +
+                        f32x2_t{be[2 * p], be[2 * p + 1]};
+            if constexpr (ACT) {   // SiLU: w / (1 + exp(-w)), exp2 domain
+                const f32x2_t x2 = w * f32x2_t{-1.4426950408889634f, -1.4426950408889634f};
+                f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])} + f32x2_t{1.0f, 1.0f};
+                w = w * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            }
+            o[2 * p] = Cvt<DT>::from_f32(w[0]);
+            o[2 * p + 1] = Cvt<DT>::from_f32(w[1]);
         }
         *reinterpret_cast<u16x8_t*>(yp + e) = o;
     };
@@ -325,15 +344,20 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
     const int threads = ((a.R * a.C8 + 63) / 64) * 64;
     const size_t lds = (size_t)a.R * C * sizeof(float2);
     const dim3 grid((unsigned)(N * a.S)), block(threads);
-    if (dtype == PGN_BF16) {
-        hipLaunchKernelGGL((pgn_gn_nhwc_stats_kernel<PGN_BF16>), grid, block, lds, s, a);
-        hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<PGN_BF16>), dim3(N * G), dim3(NH_FIN_THREADS), 0, s, a);
-        hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<PGN_BF16>), grid, block, 0, s, a);
-    } else {
-        hipLaunchKernelGGL((pgn_gn_nhwc_stats_kernel<PGN_F16>), grid, block, lds, s, a);
-        hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<PGN_F16>), dim3(N * G), dim3(NH_FIN_THREADS), 0, s, a);
-        hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<PGN_F16>), grid, block, 0, s, a);
-    }
+    const bool has_add = add_nc != nullptr;
+#define PGN_NH_LAUNCH(DT)                                                                                            \
+    do {                                                                                                             \
+        if (has_add) hipLaunchKernelGGL((pgn_gn_nhwc_stats_kernel<DT, true>), grid, block, lds, s, a);               \
+        else hipLaunchKernelGGL((pgn_gn_nhwc_stats_kernel<DT, false>), grid, block, lds, s, a);                      \
+        hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<DT>), dim3(N * G), dim3(NH_FIN_THREADS), 0, s, a);           \
+        if (has_add && act) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, true, true>), grid, block, 0, s, a);    \
+        else if (has_add) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, true, false>), grid, block, 0, s, a);     \
+        else if (act) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, false, true>), grid, block, 0, s, a);         \
+        else hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, false, false>), grid, block, 0, s, a);                 \
+    } while (0)
+    if (dtype == PGN_BF16) PGN_NH_LAUNCH(PGN_BF16);
+    else PGN_NH_LAUNCH(PGN_F16);
+#undef PGN_NH_LAUNCH
     PGN_LAUNCH_CHECK();
     return PGN_OK;
 }

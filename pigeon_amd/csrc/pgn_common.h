@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned short u16x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 // 16-bit storage <-> fp32.  Casts through __bf16 / _Float16 lower to v_cvt_* (RNE, NaN-preserving).
