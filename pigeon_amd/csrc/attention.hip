@@ -620,8 +620,257 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64_kernel(AttnArgs a) {
     }
 }
 
+
+// =====================================================================================================================
+// The 64-row kernel with a RING of three K / V buffers and counted waits (full key tiles only: Nk % 64 == 0).
+// Why: per-tile SQ counters at N = 4096 against N = 1024 (profiles/r02_attention_sq_counters_L1_L2.txt) show a fixed
+// cost of ~4.8 tile times per (batch, head, query block) workgroup, more than half of it waiting - and a workgroup's
+// share of K / V tiles that miss L2 is fixed too (a head's K / V is fetched once and shared by its Nq / 256 workgroups,
+// which run in lockstep and miss together: 4 tile loads per workgroup at either size).  In the kernel above the tile
+// prefetched at the start of tile t has to land by the MIDDLE of tile t: the compiler answers the first
+// ds_read_b64_tr_b16 it sees after an LDS-DMA with s_waitcnt vmcnt(0) (it cannot tell the LDS regions apart), and
+// __syncthreads() adds another vmcnt(0).  ~1 us is less than an HBM round trip under load, so every missing tile stalls.
+// Here tile t+2 is issued at the start of tile t and waited for with vmcnt(4) - "all but the newest tile" - at the end of
+// tile t+... i.e. two tile times later, before a raw s_barrier; the V fragment reads are inline asm (invisible to the
+// wait-count pass), issued early (block d = 0 between the two query blocks' softmax, d = 1 after it) and fenced by
+// counted lgkmcnt waits that take the fragment registers as in/out operands, so that no use can move above its wait.
+template <int DT>
+__global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
+    constexpr int DP = 64, QB = 2;
+    constexpr int TILE_BYTES = ATT_BN * DP * 2;          // 8 KiB
+    constexpr int NKS = DP / 16, NOD = DP / 32;
+    static_assert(NOD == 2, "two asm blocks of V reads");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[6 * TILE_BYTES];   // [buf 0..2][K | V]
+
+    const unsigned nwg = gridDim.x, orig = blockIdx.x;
+    const unsigned xcd = orig & 7u, qd = nwg >> 3, rm = nwg & 7u;
+    const unsigned wgid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+    const int bh = (int)(wgid / (unsigned)a.nqt), qt = (int)(wgid % (unsigned)a.nqt);
+    const int b = bh / a.H, h = bh % a.H;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    u16x8_t qf[QB][NKS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = qt * 256 + wid * 64 + qb * 32 + l31;
+        const int qrow_c = qrow < a.Nq ? qrow : a.Nq - 1;
+        const unsigned short* qp = a.q + b * a.q_sb + (long long)qrow_c * a.q_sn + h * a.q_sh + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) qf[qb][s] = *reinterpret_cast<const u16x8_t*>(qp + 16 * s);
+    }
+
+    const char* kbase = reinterpret_cast<const char*>(a.k + b * a.k_sb + h * a.k_sh);
+    const char* vbase = reinterpret_cast<const char*>(a.v + b * a.v_sb + h * a.v_sh);
+    const unsigned k_rowb = (unsigned)a.k_sn * 2u, v_rowb = (unsigned)a.v_sn * 2u;
+    const int nt = a.Nk / ATT_BN;                        // full tiles only (launcher)
+
+    unsigned ksrc[2], vsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int slot = (wid * 2 + i) * 64 + lane;
+        const int krow = slot >> 3, kch = (slot & 7) ^ ((krow >> 1) & 7);                 // inverse of k_lds_off<64>
+        const int vrow = ((slot >> 6) << 3) | ((slot >> 2) & 7), vch = (((slot >> 5) & 1) << 2) | (slot & 3);  // of v_lds_off
+        ksrc[i] = (unsigned)krow * k_rowb + (unsigned)kch * 16u;
+        vsrc[i] = (unsigned)vrow * v_rowb + (unsigned)vch * 16u;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    // four DMA instructions per wave and tile: the vmcnt arithmetic below counts on exactly that
+    auto load_tile = [&](int t, int buf) __attribute__((always_inline)) {
+        const char* gk = kbase + (size_t)t * ATT_BN * k_rowb;
+        const char* gv = vbase + (size_t)t * ATT_BN * v_rowb;
+        unsigned char* l = smem + buf * (2 * TILE_BYTES) + wid * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // keep the 32 -> 64-bit extension of the lane offsets next to their use: hoisted out of the loop they
+            // become register PAIRS, the DMA loses its scalar-base + 32-bit-offset form and the pairs spill
+            unsigned ko = ksrc[i], vo = vsrc[i];
+            asm volatile("" : "+v"(ko), "+v"(vo));
+            __builtin_amdgcn_global_load_lds((gptr_t)(gk + ko), (lptr_t)(l + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(gv + vo), (lptr_t)(l + TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+
+    int k_roff[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) k_roff[s] = k_lds_off<DP>(l31, 2 * s + hh);    // + 4096 for key block 1
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    // per-lane part of a V fragment address: 64 * (4 hh) for the lane half's keys + the transposing read's lane map
+    const unsigned v_lane = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)smem +
+                            (unsigned)(TILE_BYTES + 256 * hh + 64 * (i16 >> 2) + 32 * g16 + 8 * (i16 & 3));
+
+    f32x16_t oacc[QB][NOD];
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int d = 0; d < NOD; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
+        m_run[qb] = -1.0e30f;
+        l_run[qb] = 0.f;
+    }
+    const f32x2_t c2 = {a.c, a.c};
+
+    // prologue: the Q loads above are older than the DMAs, so "all but the newest tile" covers them and tile 0
+    load_tile(0, 0);
+    if (nt > 1) {
+        load_tile(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+#define PGN_TRV(i, OFF) "ds_read_b64_tr_b16 %" #i ", %8 offset:" #OFF "\n"
+    auto tile = [&](int t, auto buf_tag) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr int NEXT2 = (BUF + 2) % 3;
+        if (t + 2 < nt) load_tile(t + 2, NEXT2);          // buffer of tile t-1: its readers passed the last barrier
+        const unsigned char* kt = smem + BUF * (2 * TILE_BYTES);
+        const unsigned vaddr = v_lane + (unsigned)(BUF * (2 * TILE_BYTES));
+
+        f32x16_t sacc[QB][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[qb][kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                const u16x8_t kf = *reinterpret_cast<const u16x8_t*>(kt + kb * 4096 + k_roff[s]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = mfma32<DT>(kf, qf[qb][s], sacc[qb][kb]);
+            }
+        }
+
+        u16x8_t pf[QB][2][2];
+        s16x4_t f0, f1, f2, f3, f4, f5, f6, f7;            // V fragments of output dims 0..31: keys (2 j) | (2 j + 1) halves
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float tmax = sacc[qb][0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qb][kb][r]);
+            tmax = xhalf_max(tmax);
+            if (__any((tmax - m_run[qb]) * a.c > ATT_DEFER_LOG2)) {
+                const float m_new = fmaxf(m_run[qb], tmax);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * a.c);
+                l_run[qb] *= alpha;
+                const f32x2_t alpha2 = {alpha, alpha};
+#pragma unroll
+                for (int d = 0; d < NOD; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2_t o2 = {oacc[qb][d][r], oacc[qb][d][r + 1]};
+                        o2 *= alpha2;
+                        oacc[qb][d][r] = o2[0];
+                        oacc[qb][d][r + 1] = o2[1];
+                    }
+                m_run[qb] = m_new;
+            }
+            const float mc = m_run[qb] * a.c;
+            const f32x2_t nmc2 = {-mc, -mc};
+            f32x2_t lsum2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2_t x = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
+                    x = x * c2 + nmc2;
+                    f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    lsum2[(r >> 1) & 1] += p;
+                    pf[qb][kb][r >> 3][r & 7] = Cvt<DT>::from_f32(p[0]);
+                    pf[qb][kb][r >> 3][(r & 7) + 1] = Cvt<DT>::from_f32(p[1]);
+                }
+            lsum2[0] += lsum2[1];
+            l_run[qb] += lsum2[0][0] + lsum2[0][1];
+            if (qb == 0) {
+                // the first query block's scores are dead: their registers take the d = 0 fragments, whose LDS latency
+                // then hides under the second block's softmax
+                asm volatile(PGN_TRV(0, 0) PGN_TRV(1, 1024) PGN_TRV(2, 2048) PGN_TRV(3, 3072) PGN_TRV(4, 4096)
+                             PGN_TRV(5, 5120) PGN_TRV(6, 6144) PGN_TRV(7, 7168)
+                             : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3), "=&v"(f4), "=&v"(f5), "=&v"(f6), "=&v"(f7)
+                             : "v"(vaddr)
+                             : "memory");
+            }
+        }
+        s16x4_t g0, g1, g2, g3, g4, g5, g6, g7;            // output dims 32..63
+        asm volatile(PGN_TRV(0, 512) PGN_TRV(1, 1536) PGN_TRV(2, 2560) PGN_TRV(3, 3584) PGN_TRV(4, 4608) PGN_TRV(5, 5632)
+                     PGN_TRV(6, 6656) PGN_TRV(7, 7680)
+                     : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3), "=&v"(g4), "=&v"(g5), "=&v"(g6), "=&v"(g7)
+                     : "v"(vaddr)
+                     : "memory");
+        // d = 0 fragments have landed when at most the 8 newer reads are outstanding; the in/out operands pin every
+        // use of f* below this wait (hipcc moves register-only instructions across an asm s_waitcnt otherwise)
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7)
+                     :
+                     : "memory");
+        auto pv = [&](int d, const s16x4_t(&fr)[8]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const s16x4_t lo = fr[2 * (2 * kb + s2)], hi = fr[2 * (2 * kb + s2) + 1];
+                    u16x8_t vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb) oacc[qb][d] = mfma32<DT>(vf, pf[qb][kb][s2], oacc[qb][d]);
+                }
+        };
+        {
+            const s16x4_t fr[8] = {f0, f1, f2, f3, f4, f5, f6, f7};
+            pv(0, fr);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7)
+                     :
+                     : "memory");
+        {
+            const s16x4_t fr[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
+            pv(1, fr);
+        }
+        // tile t+1 (issued one tile ago) must have landed in every wave's share before anyone reads it: all but the
+        // newest tile's four DMAs retired, then the barrier.  The last tiles have nothing newer in flight.
+        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+#undef PGN_TRV
+
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using B2 = std::integral_constant<int, 2>;
+    int t = 0;
+    for (; t + 2 < nt; t += 3) {
+        tile(t, B0{});
+        tile(t + 1, B1{});
+        tile(t + 2, B2{});
+    }
+    if (t < nt) tile(t, B0{});
+    if (t + 1 < nt) tile(t + 1, B1{});
+
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l_tot = xhalf_sum(l_run[qb]);
+        const float inv = 1.0f / l_tot;
+        const int row0 = qt * 256 + wid * 64 + qb * 32;               // wave-uniform
+        att_store_block_d64<DT>(smem + wid * (32 * ATT_O_PITCH), oacc[qb], inv,
+                                a.o + b * a.o_sb + (long long)row0 * a.o_sn + h * a.o_sh, a.o_sn, a.Nq - row0, lane);
+    }
+}
+
 #ifdef PGN_TUNING_HOOKS
-int g_attn_variant = 0;  // 0 = shipped heuristic, 1 = 4 waves x 32 rows, 3 = 4 waves x 64 rows (LDS-DMA), 16 = 8 waves x 32 rows
+int g_attn_variant = 0;  // 0 = shipped heuristic, 1 = 4 waves x 32 rows, 3 = 4 waves x 64 rows (two LDS-DMA buffers), 6 = 64 rows with the three-buffer ring, 16 = 8 waves x 32 rows
 #else
 constexpr int g_attn_variant = 0;
 #endif
@@ -668,7 +917,9 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
                (long long)B * H * ((Nq + 255) / 256) >= 1024;
     if (g_attn_variant == 16 && D == 64) nw = 8;
     if (g_attn_variant == 1 || nw == 8) w64 = false;
-    if (g_attn_variant == 3) w64 = D == 64 && key_bias == nullptr;
+    if (g_attn_variant == 3 || g_attn_variant == 6) w64 = D == 64 && key_bias == nullptr;
+    // full key tiles: the three-buffer ring with counted waits; a ragged last tile keeps the two-buffer kernel
+    const bool ring = w64 && (Nk % ATT_BN) == 0 && g_attn_variant != 3;
     const int bm = w64 ? 256 : nw * 32;
     const long long nqt = (Nq + bm - 1) / bm;
     const long long blocks = (long long)B * H * nqt;
@@ -691,7 +942,8 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
 #endif
 #define PGN_ATT_LAUNCH(DT, BIAS)                                                                                  \
     do {                                                                                                          \
-        if (w64) hipLaunchKernelGGL((pgn_attn_w64_kernel<DT>), grid, block, 0, s, a);                             \
+        if (ring) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT>), grid, block, 0, s, a);                           \
+        else if (w64) hipLaunchKernelGGL((pgn_attn_w64_kernel<DT>), grid, block, 0, s, a);                        \
         else if (D == 64) {                                                                                       \
             PGN_ATT_LAUNCH_8W(DT, BIAS)                                                                           \
             hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 3, 64, false>), grid, block, 0, s, a);             \
