@@ -869,6 +869,7 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
     }
 }
 
+
 #ifdef PGN_TUNING_HOOKS
 int g_attn_variant = 0;  // 0 = shipped heuristic, 1 = 4 waves x 32 rows, 3 = 4 waves x 64 rows (two LDS-DMA buffers), 6 = 64 rows with the three-buffer ring, 16 = 8 waves x 32 rows
 #else
@@ -913,8 +914,10 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     // ... and only with at least 1024 of its 256-row workgroups (two rounds of the 512 resident ones): below that the
     // 128-row workgroups of the 32-row kernel fill the chip better (batch 1 / 2 / 4 runs, N = 4096: 716 vs 616
     // TFLOP/s at 320 workgroups, 835 vs 778 at 640, 871 vs 953 at 1280; profiles/r02_attention_small_batches.txt).
-    bool w64 = D == 64 && key_bias == nullptr && Nk >= 1024 && Nq >= 512 &&
-               (long long)B * H * ((Nq + 255) / 256) >= 1024;
+    // With full key tiles the 64-row kernel runs in its ring form, which also wins on the 4-tile key loop of
+    // cross-attention (Nk = 256: 738 / 648 against 700 / 627 TFLOP/s, profiles/r02_attention_ring_ab.txt).
+    bool w64 = D == 64 && key_bias == nullptr && Nq >= 512 && (long long)B * H * ((Nq + 255) / 256) >= 1024 &&
+               (Nk >= 1024 || (Nk >= 256 && Nk % ATT_BN == 0));
     if (g_attn_variant == 16 && D == 64) nw = 8;
     if (g_attn_variant == 1 || nw == 8) w64 = false;
     if (g_attn_variant == 3 || g_attn_variant == 6) w64 = D == 64 && key_bias == nullptr;
@@ -942,7 +945,7 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
 #endif
 #define PGN_ATT_LAUNCH(DT, BIAS)                                                                                  \
     do {                                                                                                          \
-        if (ring) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT>), grid, block, 0, s, a);                           \
+        if (ring) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT>), grid, block, 0, s, a);                      \
         else if (w64) hipLaunchKernelGGL((pgn_attn_w64_kernel<DT>), grid, block, 0, s, a);                        \
         else if (D == 64) {                                                                                       \
             PGN_ATT_LAUNCH_8W(DT, BIAS)                                                                           \

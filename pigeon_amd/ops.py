@@ -652,7 +652,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     # bias and with >= 16 key tiles goes to the 64-rows-per-wave LDS-DMA kernel
     if D != 64:
         kind = f"attention_d{D}"
-    elif key_bias is None and Nk >= 1024 and Nq >= 512 and B * heads * ((Nq + 255) // 256) >= 1024:
+    elif (key_bias is None and Nq >= 512 and B * heads * ((Nq + 255) // 256) >= 1024
+          and (Nk >= 1024 or (Nk >= 256 and Nk % 64 == 0))):
         kind = "attention_w64"
     else:
         kind = "attention"

@@ -384,10 +384,12 @@ def test_attention_rescale_branch_of_the_64_row_kernel(ops):
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,dtype", [(13, 20, 1024, 1024, torch.bfloat16), (8, 16, 2048, 1024, torch.float16),
-                                             (32, 16, 512, 1280, torch.bfloat16)],
-                         ids=["1040wgs", "1024wgs_fp16", "1024wgs_short"])
+                                             (32, 16, 512, 1280, torch.bfloat16), (16, 20, 1024, 256, torch.bfloat16),
+                                             (32, 16, 512, 320, torch.float16)],
+                         ids=["1040wgs", "1024wgs_fp16", "1024wgs_short", "cross_4_tiles", "cross_5_tiles_fp16"])
 def test_attention_64_row_kernel_more_workgroups_than_resident_slots(ops, B, H, Nq, Nk, dtype):
-    # At least two rounds of the 512 resident (batch, head, 256-row block) workgroups (two per CU): every output
+    # The ring form of the 64-row kernel (full key tiles; 16, 20, 4 and 5 tiles: every remainder of the three-buffer
+    # unrolling).  At least two rounds of the 512 resident (batch, head, 256-row block) workgroups (two per CU): every output
     # row against the fp32 oracle (per batch, to bound host memory), strided q / k / v views of one fused projection,
     # a late score spike in one batch.  (Written for a persistent form of the kernel that was measured and not kept,
     # DESIGN.md section 4; the shapes stay as coverage of multi-round launches.)
