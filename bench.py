@@ -284,13 +284,14 @@ def main():
     roofline = None
     att = {k: agg[k] for k in ("attention_w64", "attention") if k in agg}
     if att:
-        # dominant hand-written kernel: the 64-rows-per-wave kernel (the UNet's self-attention, ~93 % of the attention
-        # FLOPs); `all_head_dim_64` is the launch-weighted figure over both head-dim-64 kernels (comparable with round
-        # 1, where one kernel served every shape)
+        # dominant hand-written kernel: the 64-rows-per-wave kernel (at batch 16 every head-dim-64 launch of the UNet,
+        # self- and cross-attention); `all_head_dim_64` adds the launches the heuristic leaves to the 32-row kernel
+        # (small batches), launch-weighted
         dom = "attention_w64" if "attention_w64" in att else "attention"
         n, work, secs = att[dom]
         ach = work / secs / 1e12
-        name = {"attention_w64": "pgn_attn_w64_kernel<1>", "attention": "pgn_attn_fwd_kernel<1, false, 4, 3, 64, false>"}[dom]
+        # (full key tiles, as at every SDXL shape: the ring form of the 64-row kernel)
+        name = {"attention_w64": "pgn_attn_w64r_kernel<1>", "attention": "pgn_attn_fwd_kernel<1, false, 4, 3, 64, false>"}[dom]
         traffic, src = pmc_traffic(name)
         n_all = sum(v[0] for v in att.values())
         w_all = sum(v[1] for v in att.values())
