@@ -2,17 +2,22 @@
 // Replaces xformers.ops.memory_efficient_attention as reached from diffusers XFormersAttnProcessor
 // (enabled at Pigeon/models/lavit_for_pigeon.py:202): softmax(q k^T * scale [+ key bias]) v, head_dim 64.
 //
-// Structure (MI355X-first, not a warp-shaped port):
-//   * one 512-thread workgroup (8 wave64, 2 per SIMD) owns 256 query rows of one (batch, head); each wave
-//     owns 32 rows.  Workgroup ids are remapped so that all query tiles of a head run on one XCD and its
-//     K/V (<= 1 MiB) stay in that XCD's L2.
-//   * K/V stream through LDS in 64-key tiles, double-buffered, register-staged: the global loads of
-//     tile t+1 are issued before the MFMAs of tile t and written to LDS after them (one barrier per tile).
+// Three kernels in this file (pgn_attention_fwd picks one; measured A/B per shape: scripts/attn_ab.py):
+//   pgn_attn_w64r_kernel  head dim 64, no key bias, full key tiles, >= 1024 workgroups - every head-dim-64 launch of the
+//                         SDXL UNet at batch >= 4: 4 waves x 64 query rows, K / V by LDS-DMA through a ring of three
+//                         buffers with counted waits
+//   pgn_attn_w64_kernel   the same with two buffers and a compile-time masked last tile: ragged key counts
+//   pgn_attn_fwd_kernel   everything else (key bias, head dims 8..256, small launches): 4 waves x 32 rows,
+//                         register-staged double buffer
+// Common structure (MI355X-first, not a warp-shaped port):
+//   * workgroup ids are remapped so that all query tiles of a head run on one XCD and its K/V stay in that XCD's L2;
+//   * K/V stream through LDS in 64-key tiles, the next tile(s) in flight while the current one is computed, one
+//     barrier per tile;
 //   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (keys on the accumulator rows, the query on the lane), so
 //     every lane owns one query row: row max / sum are lane-local plus ONE permlane32 swap, and the
-//     accumulator registers are already the B operand of O^T = V^T P^T (no LDS round trip for P).
+//     accumulator registers are already the B operand of O^T = V^T P^T (no LDS round trip for P);
 //   * K tile is XOR-swizzled for conflict-free ds_read_b128; V tile is laid out in 8-key x 32-dim
-//     sub-tiles and read with ds_read_b64_tr_b16 (hardware transpose) as the A operand.
+//     sub-tiles and read with ds_read_b64_tr_b16 (hardware transpose) as the A operand;
 //   * q/k/v/out are addressed through (batch, sequence, head) element strides: the [B, N, H*64] output
 //     of to_q/to_k/to_v is consumed in place, no head_to_batch_dim copy.
 #include <type_traits>
@@ -31,8 +36,8 @@ constexpr float ATT_DEFER_LOG2 = 8.0f;
 // Head dims: the kernel is instantiated for a PADDED head dim DP of 64, 128 or 256 (256: one wavefront per SIMD, for
 // SD-1.5's 160-wide heads only); a head dim D < DP (D % 8 == 0: the token decoder's 88, SD-1.5's 40 / 80 / 160) is zero-filled up to DP on the way into registers / LDS (zero q and k columns
 // add nothing to the scores, zero v columns are never stored), so callers pass their tensors as they are.
-// a workgroup = NWAVES wave64, 32 query rows each: NWAVES = 8 (256 rows, 2 waves per SIMD) for long key sequences,
-// NWAVES = 4 (128 rows, several workgroups per CU) when the key loop is short and prologue latency dominates
+// pgn_attn_fwd_kernel: a workgroup = NWAVES wave64 of 32 query rows each; NWAVES = 4 ships (128 rows, several
+// workgroups per CU), the 8-wave geometry exists in the measurement build only
 
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
