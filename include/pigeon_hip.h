@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PGN_VERSION 100 /* 0.1.0 */
+#define PGN_VERSION 110 /* 0.1.1: + pgn_token_embed, pgn_attention_causal_fwd, pgn_groupnorm_silu_nhwc_static (additions only) */
 
 #define PGN_OK 0
 #define PGN_ERR_INVALID (-1)     /* null pointer, non-positive size, bad enum, misalignment */
