@@ -1,0 +1,38 @@
+"""Build-time invariants of the attention kernels that no run-time test can see.
+
+The ring form of the 64-row kernel (pgn_attn_w64r_kernel) orders its LDS-DMA tiles with COUNTED s_waitcnt vmcnt(4)
+waits: "all but the newest tile's four DMA instructions have retired".  That arithmetic holds only while the kernel
+issues no other vector-memory instruction inside its loop - a register spill would add scratch loads to the same
+counter and the wait would let a tile be read before it has landed (rarely, and only on some shapes).  So the kernel
+must compile without scratch; hipcc's resource-usage remarks say whether it does (cross-compiles without a GPU)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_ring_attention_kernel_has_no_scratch_and_two_waves_per_simd(tmp_path):
+    src = os.path.join(ROOT, "pigeon_amd", "csrc", "attention.hip")
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+                          "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "attention.o")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", out.stderr)
+    seen = 0
+    for blk in blocks[1:]:
+        name = blk.split()[0]
+        if "pgn_attn_w64r_kernel" not in name and "pgn_attn_w64_kernel" not in name:
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk).group(1))
+        vgprs = int(re.search(r" VGPRs: (\d+)", blk).group(1))
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", blk).group(1))
+        assert scratch == 0, f"{name}: {scratch} bytes of scratch per lane (spills break the counted vmcnt waits)"
+        assert vgprs <= 256 and occ >= 2, (name, vgprs, occ)
+    assert seen >= 4                     # bf16 + fp16 instantiations of both 64-row kernels
