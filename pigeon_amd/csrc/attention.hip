@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64_kernel(AttnArgs a) {
 // tile t+... i.e. two tile times later, before a raw s_barrier; the V fragment reads are inline asm (invisible to the
 // wait-count pass), issued early (block d = 0 between the two query blocks' softmax, d = 1 after it) and fenced by
 // counted lgkmcnt waits that take the fragment registers as in/out operands, so that no use can move above its wait.
-template <int DT>
+template <int DT, bool SUMCHK>
 __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
     constexpr int DP = 64, QB = 2;
     constexpr int TILE_BYTES = ATT_BN * DP * 2;          // 8 KiB
@@ -758,13 +758,17 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
         s16x4_t f0, f1, f2, f3, f4, f5, f6, f7;            // V fragments of output dims 0..31: keys (2 j) | (2 j + 1) halves
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            float tmax = sacc[qb][0][0];
+            // raise the reference to the exact running maximum (O, l rescaled): the rare path of both forms
+            auto raise_reference = [&]() __attribute__((always_inline)) {
+                float tmax = sacc[qb][0][0];
+                // the maximum chain starts from an opaque value: it must stay inside the rare branch (the scores
+                // are loop invariants of the sum-check loop below and would be hoisted onto the common path)
+                asm volatile("" : "+v"(tmax));
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qb][kb][r]);
-            tmax = xhalf_max(tmax);
-            if (__any((tmax - m_run[qb]) * a.c > ATT_DEFER_LOG2)) {
+                    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qb][kb][r]);
+                tmax = xhalf_max(tmax);
                 const float m_new = fmaxf(m_run[qb], tmax);
                 const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * a.c);
                 l_run[qb] *= alpha;
@@ -779,22 +783,47 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
                         oacc[qb][d][r + 1] = o2[1];
                     }
                 m_run[qb] = m_new;
-            }
-            const float mc = m_run[qb] * a.c;
-            const f32x2_t nmc2 = {-mc, -mc};
-            f32x2_t lsum2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+            };
+            f32x2_t lsum2[2];
+            auto probabilities = [&]() __attribute__((always_inline)) {
+                const float mc = m_run[qb] * a.c;
+                const f32x2_t nmc2 = {-mc, -mc};
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    f32x2_t x = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
-                    x = x * c2 + nmc2;
-                    f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                    lsum2[(r >> 1) & 1] += p;
-                    pf[qb][kb][r >> 3][r & 7] = Cvt<DT>::from_f32(p[0]);
-                    pf[qb][kb][r >> 3][(r & 7) + 1] = Cvt<DT>::from_f32(p[1]);
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2_t x = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
+                        x = __builtin_elementwise_fma(x, c2, nmc2);
+                        f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                        if (kb == 0 && r < 4) lsum2[r >> 1] = p;     // two chains, no zero-initialised adds
+                        else lsum2[(r >> 1) & 1] += p;
+                        pf[qb][kb][r >> 3][r & 7] = Cvt<DT>::from_f32(p[0]);
+                        pf[qb][kb][r >> 3][(r & 7) + 1] = Cvt<DT>::from_f32(p[1]);
+                    }
+                lsum2[0] += lsum2[1];
+            };
+            if constexpr (SUMCHK) {
+                // No row maximum on the common path: the probabilities are taken against the current reference and
+                // the lane's own sum of its 32 of them is the overflow check - it bounds every one of them, so
+                // "sum <= 2^8" keeps P inside the same range as the deferred-maximum form (and is false for the inf
+                // and NaN of scores that overflowed).  Only then is the exact maximum taken and the tile's
+                // probabilities computed again (<= 1 each).  The first tile has no reference yet and takes it first.
+                if (t == 0) raise_reference();
+                probabilities();
+                if (__any(!(lsum2[0][0] + lsum2[0][1] <= 256.0f))) {
+                    raise_reference();
+                    probabilities();
                 }
-            lsum2[0] += lsum2[1];
+            } else {
+                float tmax = sacc[qb][0][0];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[qb][kb][r]);
+                tmax = xhalf_max(tmax);
+                if (__any((tmax - m_run[qb]) * a.c > ATT_DEFER_LOG2)) raise_reference();
+                probabilities();
+            }
             l_run[qb] += lsum2[0][0] + lsum2[0][1];
             if (qb == 0) {
                 // the first query block's scores are dead: their registers take the d = 0 fragments, whose LDS latency
@@ -876,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
 
 
 #ifdef PGN_TUNING_HOOKS
-int g_attn_variant = 0;  // 0 = shipped heuristic, 1 = 4 waves x 32 rows, 3 = 4 waves x 64 rows (two LDS-DMA buffers), 6 = 64 rows with the three-buffer ring, 16 = 8 waves x 32 rows
+int g_attn_variant = 0;  // 0 = shipped heuristic, 1 = 4 waves x 32 rows, 3 = 4 waves x 64 rows (two LDS-DMA buffers), 6 = 64 rows with the three-buffer ring and a row maximum per tile, 7 = the shipped ring kernel forced, 16 = 8 waves x 32 rows
 #else
 constexpr int g_attn_variant = 0;
 #endif
@@ -925,9 +954,12 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
                (Nk >= 1024 || (Nk >= 256 && Nk % ATT_BN == 0));
     if (g_attn_variant == 16 && D == 64) nw = 8;
     if (g_attn_variant == 1 || nw == 8) w64 = false;
-    if (g_attn_variant == 3 || g_attn_variant == 6) w64 = D == 64 && key_bias == nullptr;
+    if (g_attn_variant == 3 || g_attn_variant == 6 || g_attn_variant == 7) w64 = D == 64 && key_bias == nullptr;
     // full key tiles: the three-buffer ring with counted waits; a ragged last tile keeps the two-buffer kernel
     const bool ring = w64 && (Nk % ATT_BN) == 0 && g_attn_variant != 3;
+#ifdef PGN_TUNING_HOOKS
+    const bool sumchk = g_attn_variant != 6;   // 6: the ring kernel with the row maximum on every tile
+#endif
     const int bm = w64 ? 256 : nw * 32;
     const long long nqt = (Nq + bm - 1) / bm;
     const long long blocks = (long long)B * H * nqt;
@@ -945,12 +977,18 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
 #ifdef PGN_TUNING_HOOKS
 #define PGN_ATT_LAUNCH_8W(DT, BIAS) \
     if (nw == 8) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 8, 2, 64, false>), grid, block, 0, s, a); else
+#define PGN_ATT_LAUNCH_RING_MAX(DT) \
+    if (!sumchk) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, false>), grid, block, 0, s, a); else
 #else
 #define PGN_ATT_LAUNCH_8W(DT, BIAS)
+#define PGN_ATT_LAUNCH_RING_MAX(DT)
 #endif
 #define PGN_ATT_LAUNCH(DT, BIAS)                                                                                  \
     do {                                                                                                          \
-        if (ring) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT>), grid, block, 0, s, a);                      \
+        if (ring) {                                                                                               \
+            PGN_ATT_LAUNCH_RING_MAX(DT)                                                                           \
+            hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true>), grid, block, 0, s, a);                           \
+        }                                                                                                         \
         else if (w64) hipLaunchKernelGGL((pgn_attn_w64_kernel<DT>), grid, block, 0, s, a);                        \
         else if (D == 64) {                                                                                       \
             PGN_ATT_LAUNCH_8W(DT, BIAS)                                                                           \
@@ -970,6 +1008,7 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     }
 #undef PGN_ATT_LAUNCH
 #undef PGN_ATT_LAUNCH_8W
+#undef PGN_ATT_LAUNCH_RING_MAX
     PGN_LAUNCH_CHECK();
     return PGN_OK;
 }
