@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64_kernel(AttnArgs a) {
 // tile t+... i.e. two tile times later, before a raw s_barrier; the V fragment reads are inline asm (invisible to the
 // wait-count pass), issued early (block d = 0 between the two query blocks' softmax, d = 1 after it) and fenced by
 // counted lgkmcnt waits that take the fragment registers as in/out operands, so that no use can move above its wait.
-template <int DT, bool SUMCHK>
+template <int DT, bool SUMCHK, bool PACKED = false, int PIPE = 0>
 __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
     constexpr int DP = 64, QB = 2;
     constexpr int TILE_BYTES = ATT_BN * DP * 2;          // 8 KiB
@@ -756,6 +756,20 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
 
         u16x8_t pf[QB][2][2];
         s16x4_t f0, f1, f2, f3, f4, f5, f6, f7;            // V fragments of output dims 0..31: keys (2 j) | (2 j + 1) halves
+        s16x4_t g0, g1, g2, g3, g4, g5, g6, g7;            // output dims 32..63
+        // PV of ONE query block against the fragments of output-dim block d
+        auto pv_q = [&](int qb, int d, const s16x4_t(&fr)[8]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const s16x4_t lo = fr[2 * (2 * kb + s2)], hi = fr[2 * (2 * kb + s2) + 1];
+                    u16x8_t vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    oacc[qb][d] = mfma32<DT>(vf, pf[qb][kb][s2], oacc[qb][d]);
+                }
+        };
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             // raise the reference to the exact running maximum (O, l rescaled): the rare path of both forms
@@ -787,20 +801,39 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
             f32x2_t lsum2[2];
             auto probabilities = [&]() __attribute__((always_inline)) {
                 const float mc = m_run[qb] * a.c;
-                const f32x2_t nmc2 = {-mc, -mc};
+                if constexpr (PACKED) {
+                    const f32x2_t nmc2 = {-mc, -mc};
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        f32x2_t x = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
-                        x = __builtin_elementwise_fma(x, c2, nmc2);
-                        f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                        if (kb == 0 && r < 4) lsum2[r >> 1] = p;     // two chains, no zero-initialised adds
-                        else lsum2[(r >> 1) & 1] += p;
-                        pf[qb][kb][r >> 3][r & 7] = Cvt<DT>::from_f32(p[0]);
-                        pf[qb][kb][r >> 3][(r & 7) + 1] = Cvt<DT>::from_f32(p[1]);
-                    }
-                lsum2[0] += lsum2[1];
+                        for (int r = 0; r < 16; r += 2) {
+                            f32x2_t x = {sacc[qb][kb][r], sacc[qb][kb][r + 1]};
+                            x = __builtin_elementwise_fma(x, c2, nmc2);
+                            f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                            if (kb == 0 && r < 4) lsum2[r >> 1] = p;     // two chains, no zero-initialised adds
+                            else lsum2[(r >> 1) & 1] += p;
+                            pf[qb][kb][r >> 3][r & 7] = Cvt<DT>::from_f32(p[0]);
+                            pf[qb][kb][r >> 3][(r & 7) + 1] = Cvt<DT>::from_f32(p[1]);
+                        }
+                    lsum2[0] += lsum2[1];
+                } else {
+                    // PLAIN fp32 instructions on purpose: on gfx950 v_fma_f32 / v_add_f32 / v_cvt_pk issue underneath a
+                    // running MFMA at no cost, while the packed forms (v_pk_fma_f32, v_pk_add_f32) hold the matrix
+                    // pipe for 4.6-6.5 cycles each (scripts/ubench_overlap.hip).  This file is compiled with
+                    // -fno-slp-vectorize so that the scalar statements below stay scalar.
+                    const float nmc = -mc;
+                    float ls[4];
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qb][kb][r], a.c, nmc));
+                            if (kb == 0 && r < 4) ls[r] = p;             // four chains
+                            else ls[r & 3] += p;
+                            pf[qb][kb][r >> 3][r & 7] = Cvt<DT>::from_f32(p);
+                        }
+                    lsum2[0] = f32x2_t{ls[0] + ls[2], ls[1] + ls[3]};
+                }
             };
             if constexpr (SUMCHK) {
                 // No row maximum on the common path: the probabilities are taken against the current reference and
@@ -808,8 +841,32 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
                 // "sum <= 2^8" keeps P inside the same range as the deferred-maximum form (and is false for the inf
                 // and NaN of scores that overflowed).  Only then is the exact maximum taken and the tile's
                 // probabilities computed again (<= 1 each).  The first tile has no reference yet and takes it first.
-                if (t == 0) raise_reference();
+                if constexpr (PIPE == 0) {
+                    if (t == 0) raise_reference();
+                }
                 probabilities();
+                if constexpr (PIPE == 2) {
+                    if (qb == 1) {
+                        // the first block's PV MFMAs sit between the second block's exponentials and its check: they
+                        // are independent of both, so the scheduler can issue them underneath the plain VALU work
+                        asm volatile("s_waitcnt lgkmcnt(8)"
+                                     : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7)
+                                     :
+                                     : "memory");
+                        {
+                            const s16x4_t fr[8] = {f0, f1, f2, f3, f4, f5, f6, f7};
+                            pv_q(0, 0, fr);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4), "+v"(g5), "+v"(g6), "+v"(g7)
+                                     :
+                                     : "memory");
+                        {
+                            const s16x4_t fr[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
+                            pv_q(0, 1, fr);
+                        }
+                    }
+                }
                 if (__any(!(lsum2[0][0] + lsum2[0][1] <= 256.0f))) {
                     raise_reference();
                     probabilities();
@@ -825,7 +882,18 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
                 probabilities();
             }
             l_run[qb] += lsum2[0][0] + lsum2[0][1];
-            if (qb == 0) {
+            if (PIPE == 2 && qb == 0) {
+                asm volatile(PGN_TRV(0, 0) PGN_TRV(1, 1024) PGN_TRV(2, 2048) PGN_TRV(3, 3072) PGN_TRV(4, 4096)
+                             PGN_TRV(5, 5120) PGN_TRV(6, 6144) PGN_TRV(7, 7168)
+                             : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3), "=&v"(f4), "=&v"(f5), "=&v"(f6), "=&v"(f7)
+                             : "v"(vaddr)
+                             : "memory");
+                asm volatile(PGN_TRV(0, 512) PGN_TRV(1, 1536) PGN_TRV(2, 2560) PGN_TRV(3, 3584) PGN_TRV(4, 4608)
+                             PGN_TRV(5, 5632) PGN_TRV(6, 6656) PGN_TRV(7, 7680)
+                             : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3), "=&v"(g4), "=&v"(g5), "=&v"(g6), "=&v"(g7)
+                             : "v"(vaddr)
+                             : "memory");
+            } else if (qb == 0) {
                 // the first query block's scores are dead: their registers take the d = 0 fragments, whose LDS latency
                 // then hides under the second block's softmax
                 asm volatile(PGN_TRV(0, 0) PGN_TRV(1, 1024) PGN_TRV(2, 2048) PGN_TRV(3, 3072) PGN_TRV(4, 4096)
@@ -835,7 +903,16 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
                              : "memory");
             }
         }
-        s16x4_t g0, g1, g2, g3, g4, g5, g6, g7;            // output dims 32..63
+        if constexpr (PIPE == 2) {
+            {
+                const s16x4_t fr[8] = {f0, f1, f2, f3, f4, f5, f6, f7};
+                pv_q(1, 0, fr);
+            }
+            {
+                const s16x4_t fr[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
+                pv_q(1, 1, fr);
+            }
+        } else {
         asm volatile(PGN_TRV(0, 512) PGN_TRV(1, 1536) PGN_TRV(2, 2560) PGN_TRV(3, 3584) PGN_TRV(4, 4608) PGN_TRV(5, 5632)
                      PGN_TRV(6, 6656) PGN_TRV(7, 7680)
                      : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3), "=&v"(g4), "=&v"(g5), "=&v"(g6), "=&v"(g7)
@@ -872,6 +949,7 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
             const s16x4_t fr[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
             pv(1, fr);
         }
+        }
         // tile t+1 (issued one tile ago) must have landed in every wave's share before anyone reads it: all but the
         // newest tile's four DMAs retired, then the barrier.  The last tiles have nothing newer in flight.
         if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -905,7 +983,7 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
 
 
 #ifdef PGN_TUNING_HOOKS
-int g_attn_variant = 0;  // 0 = shipped heuristic, 1 = 4 waves x 32 rows, 3 = 4 waves x 64 rows (two LDS-DMA buffers), 6 = 64 rows with the three-buffer ring and a row maximum per tile, 7 = the shipped ring kernel forced, 16 = 8 waves x 32 rows
+int g_attn_variant = 0;  // 0 = shipped heuristic, 1 = 4 waves x 32 rows, 3 = 4 waves x 64 rows (two LDS-DMA buffers), 6 = 64 rows with the three-buffer ring and a row maximum per tile, 7 = the shipped ring kernel forced, 8 / 9 / 10 = its earlier forms (packed fp32 softmax arithmetic; plain arithmetic in the old order; the same without the first-tile branch), 16 = 8 waves x 32 rows
 #else
 constexpr int g_attn_variant = 0;
 #endif
@@ -954,7 +1032,7 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
                (Nk >= 1024 || (Nk >= 256 && Nk % ATT_BN == 0));
     if (g_attn_variant == 16 && D == 64) nw = 8;
     if (g_attn_variant == 1 || nw == 8) w64 = false;
-    if (g_attn_variant == 3 || g_attn_variant == 6 || g_attn_variant == 7) w64 = D == 64 && key_bias == nullptr;
+    if (g_attn_variant == 3 || (g_attn_variant >= 6 && g_attn_variant <= 10)) w64 = D == 64 && key_bias == nullptr;
     // full key tiles: the three-buffer ring with counted waits; a ragged last tile keeps the two-buffer kernel
     const bool ring = w64 && (Nk % ATT_BN) == 0 && g_attn_variant != 3;
 #ifdef PGN_TUNING_HOOKS
@@ -978,7 +1056,10 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
 #define PGN_ATT_LAUNCH_8W(DT, BIAS) \
     if (nw == 8) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 8, 2, 64, false>), grid, block, 0, s, a); else
 #define PGN_ATT_LAUNCH_RING_MAX(DT) \
-    if (!sumchk) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, false>), grid, block, 0, s, a); else
+    if (!sumchk) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, false, true, 0>), grid, block, 0, s, a); else \
+    if (g_attn_variant == 8) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, true, 0>), grid, block, 0, s, a); else \
+    if (g_attn_variant == 9) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, false, 0>), grid, block, 0, s, a); else \
+    if (g_attn_variant == 10) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, false, 1>), grid, block, 0, s, a); else
 #else
 #define PGN_ATT_LAUNCH_8W(DT, BIAS)
 #define PGN_ATT_LAUNCH_RING_MAX(DT)
@@ -987,7 +1068,7 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     do {                                                                                                          \
         if (ring) {                                                                                               \
             PGN_ATT_LAUNCH_RING_MAX(DT)                                                                           \
-            hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true>), grid, block, 0, s, a);                           \
+            hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, false, 2>), grid, block, 0, s, a);                 \
         }                                                                                                         \
         else if (w64) hipLaunchKernelGGL((pgn_attn_w64_kernel<DT>), grid, block, 0, s, a);                        \
         else if (D == 64) {                                                                                       \

@@ -19,7 +19,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 @pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
 def test_ring_attention_kernel_has_no_scratch_and_two_waves_per_simd(tmp_path):
     src = os.path.join(ROOT, "pigeon_amd", "csrc", "attention.hip")
-    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+    # the flags of pigeon_amd/csrc/Makefile for this file (EXTRA_attention included)
+    mk = open(os.path.join(ROOT, "pigeon_amd", "csrc", "Makefile")).read()
+    extra = re.search(r"^EXTRA_attention\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    assert "-fno-slp-vectorize" in extra     # the softmax arithmetic must stay unpacked (see attention.hip)
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", *extra,
                           "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", str(tmp_path / "attention.o")],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -36,3 +40,23 @@ def test_ring_attention_kernel_has_no_scratch_and_two_waves_per_simd(tmp_path):
         assert scratch == 0, f"{name}: {scratch} bytes of scratch per lane (spills break the counted vmcnt waits)"
         assert vgprs <= 256 and occ >= 2, (name, vgprs, occ)
     assert seen >= 4                     # bf16 + fp16 instantiations of both 64-row kernels
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not available")
+def test_ring_attention_softmax_arithmetic_is_not_packed(tmp_path):
+    """On gfx950 plain fp32 VALU instructions issue underneath a running MFMA, packed fp32 ones (v_pk_fma_f32,
+    v_pk_add_f32) hold the matrix pipe (scripts/ubench_overlap.hip): the shipped ring kernel's common path must not
+    contain them.  v_pk_mul_f32 is allowed: it is the O rescale of the rare raise-the-reference branch."""
+    src = os.path.join(ROOT, "pigeon_amd", "csrc", "attention.hip")
+    mk = open(os.path.join(ROOT, "pigeon_amd", "csrc", "Makefile")).read()
+    extra = re.search(r"^EXTRA_attention\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    asm = tmp_path / "attention.s"
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", *extra,
+                          "--cuda-device-only", "-S", src, "-o", str(asm)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    text = asm.read_text()
+    m = re.search(r"^(\S*pgn_attn_w64r_kernelILi1E\S*):", text, re.M)
+    assert m, "bf16 ring kernel not found in the assembly"
+    body = text[m.start():text.index(".Lfunc_end", m.start())]
+    assert "v_mfma_f32_32x32x16_bf16" in body
+    assert "v_pk_fma_f32" not in body and "v_pk_add_f32" not in body
