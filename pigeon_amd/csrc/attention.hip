@@ -5,7 +5,9 @@
 // Three kernels in this file (pgn_attention_fwd picks one; measured A/B per shape: scripts/attn_ab.py):
 //   pgn_attn_w64r_kernel  head dim 64, no key bias, full key tiles, >= 1024 workgroups - every head-dim-64 launch of the
 //                         SDXL UNet at batch >= 4: 4 waves x 64 query rows, K / V by LDS-DMA through a ring of three
-//                         buffers with counted waits
+//                         buffers with counted waits; softmax in PLAIN fp32 instructions (they issue underneath a
+//                         running MFMA on gfx950, packed fp32 ones hold the matrix pipe: scripts/ubench_overlap.hip),
+//                         no row maximum on the common path, one query block's PV MFMAs under the other's exponentials
 //   pgn_attn_w64_kernel   the same with two buffers and a compile-time masked last tile: ragged key counts
 //   pgn_attn_fwd_kernel   everything else (key bias, head dims 8..256, small launches): 4 waves x 32 rows,
 //                         register-staged double buffer
@@ -324,7 +326,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
             m_run = m_new;
         }
         const float mc = m_run * cm;
-        // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two scores per VALU instruction
+        // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two scores per VALU instruction.  Packed instructions do not
+        // issue underneath an MFMA (see pgn_attn_w64r_kernel); with this kernel's three waves per SIMD the plain form
+        // measured the same (+-0.5 %, profiles/r02_attention_32row_plain_valu_ab.txt) and costs a few spilled registers
+        // at the 168-VGPR cap, so the packed form stays here
         const f32x2_t c2 = {HAS_BIAS ? 1.0f : a.c, HAS_BIAS ? 1.0f : a.c};
         const f32x2_t nmc2 = {-mc, -mc};
         f32x2_t lsum2[2] = {{0.f, 0.f}, {0.f, 0.f}};   // two chains: no dependent back-to-back packed adds
