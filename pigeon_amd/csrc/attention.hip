@@ -52,6 +52,9 @@ struct AttnArgs {
     unsigned short* o;
     const float* bias;
     int H, Nq, Nk, nqt, D;
+#ifdef PGN_TUNING_HOOKS
+    unsigned long long* dbg;   // measurement build: per-workgroup timestamps of the ring kernel (s_memrealtime, 100 MHz)
+#endif
     long long q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh, bias_sb;
     float c;  // scale * log2(e)
 };
@@ -661,6 +664,10 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
+#ifdef PGN_TUNING_HOOKS
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (a.dbg) ts0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     u16x8_t qf[QB][NKS];
 #pragma unroll
@@ -735,6 +742,9 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef PGN_TUNING_HOOKS
+    if (a.dbg) ts1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
 #define PGN_TRV(i, OFF) "ds_read_b64_tr_b16 %" #i ", %8 offset:" #OFF "\n"
     auto tile = [&](int t, auto buf_tag) __attribute__((always_inline)) {
@@ -975,6 +985,9 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
     }
     if (t < nt) tile(t, B0{});
     if (t + 1 < nt) tile(t + 1, B1{});
+#ifdef PGN_TUNING_HOOKS
+    if (a.dbg) ts2 = __builtin_amdgcn_s_memrealtime();
+#endif
 
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -984,6 +997,19 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
         att_store_block_d64<DT>(smem + wid * (32 * ATT_O_PITCH), oacc[qb], inv,
                                 a.o + b * a.o_sb + (long long)row0 * a.o_sn + h * a.o_sh, a.o_sn, a.Nq - row0, lane);
     }
+#ifdef PGN_TUNING_HOOKS
+    if (a.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the output stores have left
+        const unsigned long long ts3 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* d = a.dbg + (size_t)blockIdx.x * 6;
+            d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = hwid; d[5] = xcc;
+        }
+    }
+#endif
 }
 
 
@@ -999,6 +1025,9 @@ constexpr int g_attn_variant = 0;
 // Only in the measurement build (make tuning -> libpigeon_hip_tuning.so, loaded by scripts/bench_kernels.py): geometry
 // override for A/B runs in one process.  The shipped library has no such export and no mutable global state.
 extern "C" void pgn_attention_tuning(int variant) { g_attn_variant = variant; }
+static unsigned long long* g_attn_dbg = nullptr;
+// device buffer of 6 x uint64 per workgroup of the next ring-kernel launches (nullptr: off)
+extern "C" void pgn_attention_debug_buffer(void* p) { g_attn_dbg = (unsigned long long*)p; }
 #endif
 
 extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, int dtype, int B, int H,
@@ -1055,6 +1084,9 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     a.q_sb = q_sb; a.q_sn = q_sn; a.q_sh = q_sh; a.k_sb = k_sb; a.k_sn = k_sn; a.k_sh = k_sh;
     a.v_sb = v_sb; a.v_sn = v_sn; a.v_sh = v_sh; a.o_sb = o_sb; a.o_sn = o_sn; a.o_sh = o_sh; a.bias_sb = bias_sb;
     a.c = scale * 1.4426950408889634f;
+#ifdef PGN_TUNING_HOOKS
+    a.dbg = g_attn_dbg;
+#endif
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), block(nw * 64);
 #ifdef PGN_TUNING_HOOKS
