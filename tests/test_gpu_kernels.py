@@ -383,6 +383,43 @@ def test_attention_rescale_branch_of_the_64_row_kernel(ops):
     assert (want0[:, 17] - v[:1, 1500].float()).abs().max().item() < 0.25
 
 
+@pytest.mark.parametrize("pattern", ["steady_growth", "first_tile_dominates", "huge_scores", "tiny_scores"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_attention_ring_kernel_sum_check_paths(ops, pattern, dtype):
+    """The ring kernel takes no row maximum on its common path: a tile's probabilities are taken against the current
+    reference and the lane's sum of them is the overflow check (attention.hip).  Inputs that drive that check:
+    scores that grow from tile to tile (the reference has to be raised again and again, in the middle of a row block),
+    a first tile that dominates everything after it (the reference never moves again, later probabilities underflow),
+    scores of a magnitude whose exp2 overflows fp32 against a stale reference (inf in the first pass, redone), and
+    scores so small that every probability is 1.  Every output row against the fp32 oracle, the usual 2^-7 bar."""
+    B, H, N = 8, 16, 2048                         # 1024 workgroups of 256 rows, 32 full key tiles: the ring kernel
+    C = H * 64
+    g = torch.Generator().manual_seed(hash(pattern) % 1000 + (dtype == torch.float16))
+    q = torch.randn(B, N, C, generator=g)
+    k = torch.randn(B, N, C, generator=g)
+    v = torch.randn(B, N, C, generator=g)
+    if pattern == "steady_growth":
+        # key norms grow along the sequence: for queries aligned with the growth direction every few tiles hold a new
+        # maximum that is 2^8 and more above the last reference
+        ramp = torch.linspace(0.2, 6.0, N)[None, :, None]
+        direction = torch.randn(1, 1, C, generator=g).sign()
+        k = k * 0.3 + direction * ramp
+        q = q * 0.3 + direction * (torch.rand(B, N, 1, generator=g) * 2.0 - 0.5)   # some rows aligned, some opposed
+    elif pattern == "first_tile_dominates":
+        k[:, 5] = q[:, 7] * 6.0                   # key 5 (tile 0) towers over everything for query 7 ...
+        k[:, 40] = q[:, 300] * 6.0                # ... key 40 for query 300 (another row block)
+    elif pattern == "huge_scores":
+        q = q * 6.0
+        k = k * 6.0                               # |score * scale| up to ~500: exp2 against a stale reference is inf
+    else:
+        q = q * 1e-3
+        k = k * 1e-3
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), H)
+    assert torch.isfinite(got).all()
+    assert _attn_err_over_bar(got.cpu().float(), q, k, v, H) < 1.0
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,dtype", [(13, 20, 1024, 1024, torch.bfloat16), (8, 16, 2048, 1024, torch.float16),
                                              (32, 16, 512, 1280, torch.bfloat16), (16, 20, 1024, 256, torch.bfloat16),
                                              (32, 16, 512, 320, torch.float16)],
