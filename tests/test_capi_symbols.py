@@ -115,3 +115,12 @@ def test_untuned_shape_warning_names_the_tuning_command(recwarn):
     pigeon_amd.warn_if_untuned(6, 24, 40)
     pigeon_amd.warn_if_untuned(6, 24, 40)             # once per shape
     assert len(recwarn) == 1 and "tune_miopen.py --batch 3 --height 192 --width 320" in str(recwarn[0].message)
+
+
+def test_build_entry_point_checks_the_header_version():
+    """__graft_entry__.build() compares the loaded library's version with include/pigeon_hip.h (it once compared with a
+    literal that an ABI bump left behind)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "__graft_entry__.py")).read()
+    assert "PGN_VERSION" in src and not re.search(r"pgn_version\(\)\s*==\s*\d", src)
