@@ -1062,7 +1062,15 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     // TFLOP/s at 320 workgroups, 835 vs 778 at 640, 871 vs 953 at 1280; profiles/r02_attention_small_batches.txt).
     // With full key tiles the 64-row kernel runs in its ring form, which also wins on the 4-tile key loop of
     // cross-attention (Nk = 256: 738 / 648 against 700 / 627 TFLOP/s, profiles/r02_attention_ring_ab.txt).
-    bool w64 = D == 64 && key_bias == nullptr && Nq >= 512 && (long long)B * H * ((Nq + 255) / 256) >= 1024 &&
+    // Below 1024 workgroups the ring form (full key tiles) still wins where ITS rounds fill the chip better than the
+    // 32-row kernel's: efficiency of a launch = workgroups / (rounds x resident slots), 512 slots of 256 rows against
+    // 768 of 128 rows, and the ring kernel is ~1.18x faster per flop once the chip is full (end of round 2: N = 4096
+    // at 960 workgroups 985 vs 835 TFLOP/s, N = 1024 at 480 workgroups 771 vs 709, but at 640 workgroups 759 vs 776
+    // and at 320 558 vs 627; profiles/r02_attention_small_batches_final.txt).
+    const long long wg256 = (long long)B * H * ((Nq + 255) / 256), wg128 = (long long)B * H * ((Nq + 127) / 128);
+    auto fill = [](long long n, long long slots) { return (double)n / (double)(((n + slots - 1) / slots) * slots); };
+    const bool ring_fills = (Nk % ATT_BN) == 0 && 1.18 * fill(wg256, 512) > fill(wg128, 768);
+    bool w64 = D == 64 && key_bias == nullptr && Nq >= 512 && (wg256 >= 1024 || ring_fills) &&
                (Nk >= 1024 || (Nk >= 256 && Nk % ATT_BN == 0));
     if (g_attn_variant == 16 && D == 64) nw = 8;
     if (g_attn_variant == 1 || nw == 8) w64 = false;
