@@ -2,13 +2,14 @@
 // Replaces xformers.ops.memory_efficient_attention as reached from diffusers XFormersAttnProcessor
 // (enabled at Pigeon/models/lavit_for_pigeon.py:202): softmax(q k^T * scale [+ key bias]) v, head_dim 64.
 //
-// Three kernels in this file (pgn_attention_fwd picks one; measured A/B per shape: scripts/attn_ab.py):
+// Two kernels ship from this file (pgn_attention_fwd picks one; measured A/B per shape: scripts/attn_ab.py):
 //   pgn_attn_w64r_kernel  head dim 64, no key bias, full key tiles, >= 1024 workgroups - every head-dim-64 launch of the
 //                         SDXL UNet at batch >= 4: 4 waves x 64 query rows, K / V by LDS-DMA through a ring of three
 //                         buffers with counted waits; softmax in PLAIN fp32 instructions (they issue underneath a
 //                         running MFMA on gfx950, packed fp32 ones hold the matrix pipe: scripts/ubench_overlap.hip),
 //                         no row maximum on the common path, one query block's PV MFMAs under the other's exponentials
-//   pgn_attn_w64_kernel   the same with two buffers and a compile-time masked last tile: ragged key counts
+//                         (a ragged key count: the same kernel with a masked last tile);
+//                         its two-buffer predecessor pgn_attn_w64_kernel is compiled into the measurement build only
 //   pgn_attn_fwd_kernel   everything else (key bias, head dims 8..256, small launches): 4 waves x 32 rows,
 //                         register-staged double buffer
 // Common structure (MI355X-first, not a warp-shaped port):
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void pgn_attn_fwd_kernel(AttnArg
     }
 }
 
+#ifdef PGN_TUNING_HOOKS   // the ring kernel below replaced this one everywhere; kept for A/B runs (variant 3)
 // =====================================================================================================================
 // The UNet's shape class (head dim 64, no key bias): 4 wavefronts x 64 query rows, K / V tiles by LDS-DMA.
 //   * a wavefront owns two 32-row query blocks: every K / V fragment read from LDS feeds two MFMAs (half the LDS read
@@ -634,6 +636,8 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64_kernel(AttnArgs a) {
 }
 
 
+#endif  // PGN_TUNING_HOOKS
+
 // =====================================================================================================================
 // The 64-row kernel with a RING of three K / V buffers and counted waits (full key tiles only: Nk % 64 == 0).
 // Why: per-tile SQ counters at N = 4096 against N = 1024 (profiles/r02_attention_sq_counters_L1_L2.txt) show a fixed
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64_kernel(AttnArgs a) {
 // tile t+... i.e. two tile times later, before a raw s_barrier; the V fragment reads are inline asm (invisible to the
 // wait-count pass), issued early (block d = 0 between the two query blocks' softmax, d = 1 after it) and fenced by
 // counted lgkmcnt waits that take the fragment registers as in/out operands, so that no use can move above its wait.
-template <int DT, bool SUMCHK, bool PACKED = false, int PIPE = 0>
+template <int DT, bool SUMCHK, bool PACKED = false, int PIPE = 0, bool RAGGED = false>
 __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
     constexpr int DP = 64, QB = 2;
     constexpr int TILE_BYTES = ATT_BN * DP * 2;          // 8 KiB
@@ -682,7 +686,9 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
     const char* kbase = reinterpret_cast<const char*>(a.k + b * a.k_sb + h * a.k_sh);
     const char* vbase = reinterpret_cast<const char*>(a.v + b * a.v_sb + h * a.v_sh);
     const unsigned k_rowb = (unsigned)a.k_sn * 2u, v_rowb = (unsigned)a.v_sn * 2u;
-    const int nt = a.Nk / ATT_BN;                        // full tiles only (launcher)
+    // RAGGED: the last tile holds rem < 64 keys (its missing rows re-read row rem - 1, their scores are masked to -inf)
+    const int nt = RAGGED ? (a.Nk + ATT_BN - 1) / ATT_BN : a.Nk / ATT_BN;
+    const int rem = a.Nk - (nt - 1) * ATT_BN;
 
     unsigned ksrc[2], vsrc[2];
 #pragma unroll
@@ -705,6 +711,15 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
             // keep the 32 -> 64-bit extension of the lane offsets next to their use: hoisted out of the loop they
             // become register PAIRS, the DMA loses its scalar-base + 32-bit-offset form and the pairs spill
             unsigned ko = ksrc[i], vo = vsrc[i];
+            if constexpr (RAGGED) {
+                if (t == nt - 1) {                               // once per workgroup: clamp the rows past the end
+                    const int slot = (wid * 2 + i) * 64 + lane;
+                    const int krow = slot >> 3, kch = (slot & 7) ^ ((krow >> 1) & 7);
+                    const int vrow = ((slot >> 6) << 3) | ((slot >> 2) & 7), vch = (((slot >> 5) & 1) << 2) | (slot & 3);
+                    ko = (unsigned)min(krow, rem - 1) * k_rowb + (unsigned)kch * 16u;
+                    vo = (unsigned)min(vrow, rem - 1) * v_rowb + (unsigned)vch * 16u;
+                }
+            }
             asm volatile("" : "+v"(ko), "+v"(vo));
             __builtin_amdgcn_global_load_lds((gptr_t)(gk + ko), (lptr_t)(l + i * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(gv + vo), (lptr_t)(l + TILE_BYTES + i * 1024), 16, 0, 0);
@@ -747,8 +762,9 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
 #endif
 
 #define PGN_TRV(i, OFF) "ds_read_b64_tr_b16 %" #i ", %8 offset:" #OFF "\n"
-    auto tile = [&](int t, auto buf_tag) __attribute__((always_inline)) {
+    auto tile = [&](int t, auto buf_tag, auto maybe_last_tag) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
+        constexpr bool MAYBE_LAST = decltype(maybe_last_tag)::value;
         constexpr int NEXT2 = (BUF + 2) % 3;
         if (t + 2 < nt) load_tile(t + 2, NEXT2);          // buffer of tile t-1: its readers passed the last barrier
         const unsigned char* kt = smem + BUF * (2 * TILE_BYTES);
@@ -769,6 +785,19 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
             }
         }
 
+        if constexpr (RAGGED && MAYBE_LAST) {
+            if (t == nt - 1) {                                   // wave-uniform; key of sacc[.][kb][r] = kb*32 + (r&3) + 8*(r>>2) + 4*hh
+                int lim = rem - 4 * hh;
+                asm volatile("" : "+v"(lim));                   // the 32 compare masks are loop invariants: keep them in here
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (kb * 32 + (r & 3) + 8 * (r >> 2) >= lim) sacc[qb][kb][r] = -INFINITY;
+            }
+        }
         u16x8_t pf[QB][2][2];
         s16x4_t f0, f1, f2, f3, f4, f5, f6, f7;            // V fragments of output dims 0..31: keys (2 j) | (2 j + 1) halves
         s16x4_t g0, g1, g2, g3, g4, g5, g6, g7;            // output dims 32..63
@@ -977,14 +1006,17 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
     using B2 = std::integral_constant<int, 2>;
+    // RAGGED: the last tile is the third of the last full round (nt % 3 == 0) or one of the two remainder tiles; those
+    // three tile bodies carry the masking code behind a wave-uniform "is this the last tile" branch
+    using ML = std::integral_constant<bool, RAGGED>;
     int t = 0;
     for (; t + 2 < nt; t += 3) {
-        tile(t, B0{});
-        tile(t + 1, B1{});
-        tile(t + 2, B2{});
+        tile(t, B0{}, std::false_type{});
+        tile(t + 1, B1{}, std::false_type{});
+        tile(t + 2, B2{}, ML{});
     }
-    if (t < nt) tile(t, B0{});
-    if (t + 1 < nt) tile(t + 1, B1{});
+    if (t < nt) tile(t, B0{}, ML{});
+    if (t + 1 < nt) tile(t + 1, B1{}, ML{});
 #ifdef PGN_TUNING_HOOKS
     if (a.dbg) ts2 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1076,7 +1108,8 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     if (g_attn_variant == 1 || nw == 8) w64 = false;
     if (g_attn_variant == 3 || (g_attn_variant >= 6 && g_attn_variant <= 10)) w64 = D == 64 && key_bias == nullptr;
     // full key tiles: the three-buffer ring with counted waits; a ragged last tile keeps the two-buffer kernel
-    const bool ring = w64 && (Nk % ATT_BN) == 0 && g_attn_variant != 3;
+    const bool ring = w64 && g_attn_variant != 3;                        // every shape the 64-row class takes
+    const bool ragged = (Nk % ATT_BN) != 0;                              // ... a ragged key count in its masked-last-tile form
 #ifdef PGN_TUNING_HOOKS
     const bool sumchk = g_attn_variant != 6;   // 6: the ring kernel with the row maximum on every tile
 #endif
@@ -1100,6 +1133,8 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
 #ifdef PGN_TUNING_HOOKS
 #define PGN_ATT_LAUNCH_8W(DT, BIAS) \
     if (nw == 8) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 8, 2, 64, false>), grid, block, 0, s, a); else
+#define PGN_ATT_LAUNCH_W64_2BUF(DT) \
+    else if (w64) hipLaunchKernelGGL((pgn_attn_w64_kernel<DT>), grid, block, 0, s, a);
 #define PGN_ATT_LAUNCH_RING_MAX(DT) \
     if (!sumchk) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, false, true, 0>), grid, block, 0, s, a); else \
     if (g_attn_variant == 8) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, true, 0>), grid, block, 0, s, a); else \
@@ -1108,14 +1143,16 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
 #else
 #define PGN_ATT_LAUNCH_8W(DT, BIAS)
 #define PGN_ATT_LAUNCH_RING_MAX(DT)
+#define PGN_ATT_LAUNCH_W64_2BUF(DT)
 #endif
 #define PGN_ATT_LAUNCH(DT, BIAS)                                                                                  \
     do {                                                                                                          \
         if (ring) {                                                                                               \
             PGN_ATT_LAUNCH_RING_MAX(DT)                                                                           \
-            hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, false, 2>), grid, block, 0, s, a);                 \
+            if (ragged) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, false, 2, true>), grid, block, 0, s, a); \
+            else hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, false, 2>), grid, block, 0, s, a);            \
         }                                                                                                         \
-        else if (w64) hipLaunchKernelGGL((pgn_attn_w64_kernel<DT>), grid, block, 0, s, a);                        \
+        PGN_ATT_LAUNCH_W64_2BUF(DT)                                                                               \
         else if (D == 64) {                                                                                       \
             PGN_ATT_LAUNCH_8W(DT, BIAS)                                                                           \
             hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 4, 3, 64, false>), grid, block, 0, s, a);             \
@@ -1135,6 +1172,7 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
 #undef PGN_ATT_LAUNCH
 #undef PGN_ATT_LAUNCH_8W
 #undef PGN_ATT_LAUNCH_RING_MAX
+#undef PGN_ATT_LAUNCH_W64_2BUF
     PGN_LAUNCH_CHECK();
     return PGN_OK;
 }

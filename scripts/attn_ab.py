@@ -13,6 +13,8 @@ from pigeon_amd import ops
 variants = [int(v) for v in sys.argv[1:]] or [0]
 Bp = int(os.environ.get("BP", "32"))
 shapes = (("self_L1", 10, 4096, 4096), ("self_L2", 20, 1024, 1024), ("cross_L1", 10, 4096, 256), ("cross_L2", 20, 1024, 256))
+if os.environ.get("SHAPES") == "c2":   # BASELINE configs[2]: 1216x832 images, latent 152x104 (ragged key counts)
+    shapes = (("self_L1", 10, 3952, 3952), ("self_L2", 20, 988, 988), ("cross_L1", 10, 3952, 256), ("cross_L2", 20, 988, 256))
 weights = {"self_L1": 10 * 2, "self_L2": 60 * 2, "cross_L1": 10, "cross_L2": 60}   # launches per UNet forward (cross: half batch)
 
 def check(var):

@@ -383,6 +383,30 @@ def test_attention_rescale_branch_of_the_64_row_kernel(ops):
     assert (want0[:, 17] - v[:1, 1500].float()).abs().max().item() < 0.25
 
 
+@pytest.mark.parametrize("Nk", [1030, 1100, 1160, 1217], ids=["17_tiles_rem6", "18_tiles_rem12", "19_tiles_rem8", "20_tiles_rem1"])
+def test_attention_ring_kernel_ragged_last_tile(ops, Nk):
+    """Ragged key counts on the ring kernel: the last tile (in ring buffer 1, 2, 0 and 1 for these tile counts: every
+    position the masked tile body is instantiated at) re-reads its last real row for the missing ones and masks their
+    scores to -inf.  The very last key carries a spike for one query (the reference is raised inside the masked tile),
+    the padding rows of V are never reached.  Every output row against the fp32 oracle."""
+    B, H, Nq = 8, 16, 2048                        # 1024 workgroups of 256 rows: the 64-row class
+    C = H * 64
+    g = torch.Generator().manual_seed(Nk)
+    q = torch.randn(B, Nq, C, generator=g)
+    k = torch.randn(B, Nk, C, generator=g)
+    v = torch.randn(B, Nk, C, generator=g)
+    k[:, Nk - 1] = q[:, 33] * 3.0
+    q, k, v = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    # k / v as the tail of a larger buffer: what follows the last real row in memory is NaN, not zeros
+    kbuf = torch.full((B, Nk + 70, C), float("nan"), dtype=torch.bfloat16)
+    vbuf = torch.full((B, Nk + 70, C), float("nan"), dtype=torch.bfloat16)
+    kbuf[:, :Nk] = k
+    vbuf[:, :Nk] = v
+    got = ops.attention(q.to(DEV), kbuf.to(DEV)[:, :Nk], vbuf.to(DEV)[:, :Nk], H)
+    assert torch.isfinite(got).all()
+    assert _attn_err_over_bar(got.cpu().float(), q, k, v, H) < 1.0
+
+
 @pytest.mark.parametrize("pattern", ["steady_growth", "first_tile_dominates", "huge_scores", "tiny_scores"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_attention_ring_kernel_sum_check_paths(ops, pattern, dtype):
