@@ -1101,9 +1101,8 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     // and at 320 558 vs 627; profiles/r02_attention_small_batches_final.txt).
     const long long wg256 = (long long)B * H * ((Nq + 255) / 256), wg128 = (long long)B * H * ((Nq + 127) / 128);
     auto fill = [](long long n, long long slots) { return (double)n / (double)(((n + slots - 1) / slots) * slots); };
-    const bool ring_fills = (Nk % ATT_BN) == 0 && 1.18 * fill(wg256, 512) > fill(wg128, 768);
-    bool w64 = D == 64 && key_bias == nullptr && Nq >= 512 && (wg256 >= 1024 || ring_fills) &&
-               (Nk >= 1024 || (Nk >= 256 && Nk % ATT_BN == 0));
+    const bool ring_fills = 1.18 * fill(wg256, 512) > fill(wg128, 768);
+    bool w64 = D == 64 && key_bias == nullptr && Nq >= 512 && (wg256 >= 1024 || ring_fills) && Nk >= 256;
     if (g_attn_variant == 16 && D == 64) nw = 8;
     if (g_attn_variant == 1 || nw == 8) w64 = false;
     if (g_attn_variant == 3 || (g_attn_variant >= 6 && g_attn_variant <= 10)) w64 = D == 64 && key_bias == nullptr;
