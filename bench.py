@@ -291,7 +291,7 @@ def main():
         n, work, secs = att[dom]
         ach = work / secs / 1e12
         # (full key tiles, as at every SDXL shape: the ring form of the 64-row kernel)
-        name = {"attention_w64": "pgn_attn_w64r_kernel<1, true, false, 2>", "attention": "pgn_attn_fwd_kernel<1, false, 4, 3, 64, false>"}[dom]
+        name = {"attention_w64": "pgn_attn_w64r_kernel<1, true, false, 2, false>", "attention": "pgn_attn_fwd_kernel<1, false, 4, 3, 64, false>"}[dom]
         traffic, src = pmc_traffic(name)
         if traffic is None and dom == "attention_w64":   # summaries taken before the kernel got its later template parameters
             traffic, src = pmc_traffic("pgn_attn_w64r_kernel<1")
