@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64_kernel(AttnArgs a) {
 #endif  // PGN_TUNING_HOOKS
 
 // =====================================================================================================================
-// The 64-row kernel with a RING of three K / V buffers and counted waits (full key tiles only: Nk % 64 == 0).
+// The 64-row kernel with a RING of three K / V buffers and counted waits (RAGGED: a masked last tile for Nk % 64 != 0).
 // Why: per-tile SQ counters at N = 4096 against N = 1024 (profiles/r02_attention_sq_counters_L1_L2.txt) show a fixed
 // cost of ~4.8 tile times per (batch, head, query block) workgroup, more than half of it waiting - and a workgroup's
 // share of K / V tiles that miss L2 is fixed too (a head's K / V is fetched once and shared by its Nq / 256 workgroups,
@@ -651,6 +651,12 @@ __global__ __launch_bounds__(256, 2) void pgn_attn_w64_kernel(AttnArgs a) {
 // tile t+... i.e. two tile times later, before a raw s_barrier; the V fragment reads are inline asm (invisible to the
 // wait-count pass), issued early (block d = 0 between the two query blocks' softmax, d = 1 after it) and fenced by
 // counted lgkmcnt waits that take the fragment registers as in/out operands, so that no use can move above its wait.
+// Template parameters: the shipped instantiations are <DT, SUMCHK = true, PACKED = false, PIPE = 2, RAGGED = false / true>;
+//   SUMCHK  no row maximum on the common path (the lane's sum of its 32 probabilities is the overflow check)
+//   PACKED  softmax arithmetic in packed fp32 instructions (measurement build only: they do not issue under an MFMA)
+//   PIPE    0: per-block order + first-tile branch, 1: no first-tile branch, 2: both V fragment blocks read before the
+//           second query block's softmax and the first block's PV MFMAs placed between its exponentials and its check
+// (the earlier forms stay selectable in the measurement build so that every A/B in profiles/ can be repeated).
 template <int DT, bool SUMCHK, bool PACKED = false, int PIPE = 0, bool RAGGED = false>
 __global__ __launch_bounds__(256, 2) void pgn_attn_w64r_kernel(AttnArgs a) {
     constexpr int DP = 64, QB = 2;
