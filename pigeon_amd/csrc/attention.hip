@@ -1140,11 +1140,11 @@ extern "C" int pgn_attention_fwd(const void* q, const void* k, const void* v, vo
     if (nw == 8) hipLaunchKernelGGL((pgn_attn_fwd_kernel<DT, BIAS, 8, 2, 64, false>), grid, block, 0, s, a); else
 #define PGN_ATT_LAUNCH_W64_2BUF(DT) \
     else if (w64) hipLaunchKernelGGL((pgn_attn_w64_kernel<DT>), grid, block, 0, s, a);
-#define PGN_ATT_LAUNCH_RING_MAX(DT) \
-    if (!sumchk) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, false, true, 0>), grid, block, 0, s, a); else \
-    if (g_attn_variant == 8) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, true, 0>), grid, block, 0, s, a); else \
-    if (g_attn_variant == 9) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, false, 0>), grid, block, 0, s, a); else \
-    if (g_attn_variant == 10) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, false, 1>), grid, block, 0, s, a); else
+#define PGN_ATT_LAUNCH_RING_MAX(DT) /* the earlier forms take full key tiles only */ \
+    if (!ragged && !sumchk) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, false, true, 0>), grid, block, 0, s, a); else \
+    if (!ragged && g_attn_variant == 8) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, true, 0>), grid, block, 0, s, a); else \
+    if (!ragged && g_attn_variant == 9) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, false, 0>), grid, block, 0, s, a); else \
+    if (!ragged && g_attn_variant == 10) hipLaunchKernelGGL((pgn_attn_w64r_kernel<DT, true, false, 1>), grid, block, 0, s, a); else
 #else
 #define PGN_ATT_LAUNCH_8W(DT, BIAS)
 #define PGN_ATT_LAUNCH_RING_MAX(DT)
