@@ -407,6 +407,34 @@ def test_attention_ring_kernel_ragged_last_tile(ops, Nk):
     assert _attn_err_over_bar(got.cpu().float(), q, k, v, H) < 1.0
 
 
+def test_attention_64_row_class_random_shapes(ops):
+    """Twenty seeded random shapes inside the 64-row class (head dim 64, no bias, Nq >= 512, Nk >= 256, enough
+    workgroups): query counts that are not multiples of 256, every remainder of the key count modulo 64 and of the tile
+    count modulo 3, strided q / k / v views of a fused projection.  Every output row against the fp32 oracle."""
+    rng = torch.Generator().manual_seed(20251111)
+    for case in range(20):
+        Nq = int(torch.randint(512, 1400, (1,), generator=rng))
+        Nk = int(torch.randint(256, 1400, (1,), generator=rng))
+        if case % 4 == 0:
+            Nk = Nq                                   # self-attention through one fused qkv buffer
+        H = int(torch.randint(2, 6, (1,), generator=rng)) * 4
+        B = (1024 + H * ((Nq + 255) // 256) - 1) // (H * ((Nq + 255) // 256))   # >= 1024 workgroups of 256 rows
+        C = H * 64
+        if Nk == Nq:
+            qkv = (torch.randn(B, Nq, 3 * C, generator=rng) * 1.2).bfloat16()
+            q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+            dq = qkv.to(DEV)
+            got = ops.attention(dq[..., :C], dq[..., C:2 * C], dq[..., 2 * C:], H)
+        else:
+            q = (torch.randn(B, Nq, C, generator=rng) * 1.2).bfloat16()
+            kv = (torch.randn(B, Nk, 2 * C, generator=rng) * 1.2).bfloat16()
+            k, v = kv[..., :C], kv[..., C:]
+            dkv = kv.to(DEV)
+            got = ops.attention(q.to(DEV), dkv[..., :C], dkv[..., C:], H)
+        err = _attn_err_over_bar(got.cpu().float(), q, k, v, H)
+        assert err < 1.0, (case, B, H, Nq, Nk, err)
+
+
 @pytest.mark.parametrize("pattern", ["steady_growth", "first_tile_dominates", "huge_scores", "tiny_scores"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_attention_ring_kernel_sum_check_paths(ops, pattern, dtype):
