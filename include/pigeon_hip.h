@@ -169,8 +169,16 @@ int pgn_groupnorm_silu_ex(const void* x, int x_dtype, void* y, int y_dtype, cons
  * logical [N, C, H, W]), the layout the MIOpen / CK convolution kernels compute in — keeping the UNet / VAE in it
  * removes the NCHW<->NHWC transposes MIOpen otherwise runs around every convolution and makes the [B, HW, C] view of
  * diffusers Transformer2DModel free.  Same reference call sites and arithmetic as pgn_groupnorm_silu_ex (add_nc as
- * there).  Three launches (per-chunk per-channel partial statistics -> per-group mean / rstd -> apply), deterministic;
- * the workspace (pgn_groupnorm_nhwc_workspace_bytes, 8-byte aligned, contents irrelevant) is mandatory.
+ * there).  Three launches (per-chunk per-channel partial statistics -> per-group mean / rstd -> apply: 2 reads + 1
+ * write), or, for tensors of up to 32 MiB whose y does not overlap x (C <= 4096, G <= 64), ONE launch behind a small
+ * memset that reads and writes the tensor once: each workgroup keeps its rows in registers and the workgroups of a
+ * sample exchange per-group partial sums inside the launch (agent-scope hand-off, bounded wait with a recompute safety
+ * net: no dependence on dispatch order).  Both forms are deterministic (run-to-run bit-identical, no float atomics);
+ * they differ from each other in the last bit of some outputs (two summation orders).  Environment, read on every
+ * call: PGN_GN_NHWC_ONEPASS=0 keeps the three launches for every shape, =1 takes the one-launch form wherever the
+ * shape allows (it is slower than three passes on large tensors: DESIGN.md section 4).
+ * The workspace (pgn_groupnorm_nhwc_workspace_bytes, 8-byte aligned, contents irrelevant) is mandatory and must not be
+ * shared by calls that may run concurrently.
  * bf16 / f16, C % 8 == 0, C <= 8192, C / G <= 128.  Algorithmic bytes as pgn_groupnorm_silu. */
 size_t pgn_groupnorm_nhwc_workspace_bytes(int N, int C, int HW, int G);
 int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const void* gamma, const void* beta, int affine_dtype,
@@ -182,7 +190,7 @@ int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const void* gamma
  * of diffusers CrossAttnUpBlock2D.forward / UpBlock2D.forward (unet_2d_blocks.py, reached from
  * lavit_for_pigeon.py:752-757) together with the `norm1` + SiLU of the ResnetBlock2D that consumes it: the
  * concatenated tensor is never written.  Bit-identical to pgn_groupnorm_silu_nhwc on the materialised concatenation
- * (same per-channel partial sums in the same order); groups may straddle the boundary.  C1 % 8 == 0, C2 % 8 == 0,
+ * (same partial sums in the same order, same choice of form); groups may straddle the boundary.  C1 % 8 == 0, C2 % 8 == 0,
  * other limits and the workspace (query with C = C1 + C2) as above.  Algorithmic bytes: 2 * N*HW*(C1+C2) * 2,
  * against 4 * ... for cat + GroupNorm. */
 int pgn_groupnorm_silu_nhwc_cat(const void* x1, int C1, const void* x2, int C2, void* y, int dtype, const void* gamma,

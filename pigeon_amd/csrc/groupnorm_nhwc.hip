@@ -16,6 +16,8 @@
 // that second read HBM itself serves is not measurable here.
 #include "pgn_common.h"
 
+#include <cstdint>
+#include <cstdlib>
 #include <mutex>
 
 namespace {
@@ -40,6 +42,13 @@ struct NhArgs {
     int act;
     float2* part;    // [N][S][C]
     float2* stats;   // [N][G]
+    // one-pass form only
+    unsigned int* arrived;           // [N] workgroups of the sample that have published (zeroed by the launch function)
+    unsigned long long* gpart;       // [N][S][G] {sum, sum of squares} about the group pivot, one 8-byte word each
+    unsigned int timeout;            // bound of the wait, in s_memrealtime ticks (100 MHz)
+#ifdef PGN_TUNING_HOOKS
+    unsigned long long* dbg;         // measurement build: [workgroups][8] s_memrealtime stamps, or nullptr
+#endif
 };
 
 __device__ __forceinline__ float nh_param(const void* p, int dt, size_t i, float dflt) {
@@ -270,8 +279,262 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One-pass form: 1 read + 1 write of the tensor.  A workgroup keeps its row chunk in registers (NH_OP_ROWS 16-byte
+// loads per lane), publishes its per-group partial sums, waits until every workgroup of its sample has published,
+// reduces the S x G partials in a fixed order itself and applies from registers.  The statistics are pivot-shifted sums
+// about ONE pivot per (sample, group) - the group's first channel in row 0, which every workgroup can read for itself -
+// so that a workgroup's contribution is G words, not C.
+//
+// Visibility between workgroups (other CUs, other XCDs) follows the guide's counter hand-off: the partials are 8-byte
+// agent-scope atomic stores (write-through), every storing wave drains vmcnt, a workgroup barrier, then one lane's
+// agent-scope add on the sample's counter; the consumer polls that counter relaxed from one lane, runs ONE agent-scope
+// acquire, drains, barrier, and only then loads the partials (as agent-scope atomic loads as well).  x, gamma, beta and
+// add_nc are written by nobody in the launch; y is written and never read.
+//
+// Progress does not depend on dispatch order or residency: the wait is bounded (a.timeout), and a workgroup whose wait
+// runs out computes the missing chunks' partials itself from global memory with the same arithmetic in the same order
+// (bit-identical words; it also stores them, which is a rewrite of identical values).  The launch function only picks
+// this form when a sample's S workgroups fit the chip several times over (and, by default, only for tensors of up to
+// NH_OP_MAX_BYTES: see nh_run), so the bounded path is a safety net, and it needs x and y not to overlap (the pivot row and, in the safety net, other chunks are read after peers may have
+// written theirs).
+typedef __attribute__((address_space(1))) unsigned long long nh_gu64;
+typedef __attribute__((address_space(1))) unsigned int nh_gu32;
+constexpr int NH_OP_ROWS = 16;
+constexpr int NH_OP_MAX_G = 64;
+constexpr size_t NH_OP_MAX_BYTES = (size_t)32 << 20;   // tensors up to this size take the one-pass form by default
+
+template <int DT, bool HAS_ADD, bool ACT>
+__global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_onepass_kernel(NhArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float2 sh[];
+    float2* shc = sh;                                             // [R][C] lane sums, then row 0 = per-channel sums
+    float2* shL = shc + (size_t)a.R * a.C;                        // [L][G] chunk-lane sums of the S-reduction
+    float2* shS = shL + blockDim.x;                               // [G] mean, rstd
+    float* shP = reinterpret_cast<float*>(shS + NH_OP_MAX_G);     // [G] pivots
+    int* shFlag = reinterpret_cast<int*>(shP + NH_OP_MAX_G);
+    const int n = blockIdx.x / a.S, sc = blockIdx.x % a.S;
+    const int t = threadIdx.x;
+#ifdef PGN_TUNING_HOOKS
+#define NH_STAMP(k)                                                                                                  \
+    do {                                                                                                             \
+        if (a.dbg != nullptr && t == 0) a.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();      \
+    } while (0)
+#else
+#define NH_STAMP(k) do { } while (0)
+#endif
+    NH_STAMP(0);
+    const int r = t / a.C8, cc = t - r * a.C8;
+    const bool active = r < a.R;
+    int pitch = 0;
+    const unsigned short* xp = nullptr;
+    float tadd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tadd[j] = 0.f;
+    // own chunk: every load issued before anything else needs its data
+    u16x8_t v[NH_OP_ROWS];
+    int nv = 0;
+    const int row0 = sc * a.rows, row1 = min(a.HW, row0 + a.rows);
+    if (active) {
+        xp = nh_lane_src(a, n, cc * 8, &pitch);
+        if (HAS_ADD) nh_param8(a.addnc, a.add_dt, (size_t)n * a.C + cc * 8, 0.f, tadd);
+        const int first = row0 + r;
+        nv = first < row1 ? (row1 - first + a.R - 1) / a.R : 0;
+#pragma unroll
+        for (int i = 0; i < NH_OP_ROWS; ++i)
+            if (i < nv) v[i] = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(first + i * a.R) * pitch);
+    }
+    for (int g = t; g < a.G; g += blockDim.x) {                   // one pivot per (sample, group)
+        const int c0 = g * a.cpg;
+        int pp;
+        float p = Cvt<DT>::to_f32(*nh_lane_src(a, n, c0, &pp));
+        if (HAS_ADD) p = Cvt<DT>::to_f32(Cvt<DT>::from_f32(p + nh_param(a.addnc, a.add_dt, (size_t)n * a.C + c0, 0.f)));
+        shP[g] = p;
+    }
+    __syncthreads();
+    float piv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) piv[j] = active ? shP[(cc * 8 + j) / a.cpg] : 0.f;
+
+    f32x2_t s2[4], q2[4];
+    auto clear = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { s2[p] = f32x2_t{0.f, 0.f}; q2[p] = f32x2_t{0.f, 0.f}; }
+    };
+    auto accum = [&](const u16x8_t& w) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            f32x2_t f = {Cvt<DT>::to_f32(w[2 * p]), Cvt<DT>::to_f32(w[2 * p + 1])};
+            if constexpr (HAS_ADD) {
+                f += f32x2_t{tadd[2 * p], tadd[2 * p + 1]};
+                f = f32x2_t{Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[0])), Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[1]))};
+            }
+            const f32x2_t d = f - f32x2_t{piv[2 * p], piv[2 * p + 1]};
+            s2[p] += d;
+            q2[p] += d * d;
+        }
+    };
+    // lanes' sums -> per-channel -> per-group, published as chunk `chunk` of the sample; ends behind a barrier with
+    // every storing wave drained
+    auto fold_publish = [&](int chunk) {
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                shc[(size_t)r * a.C + cc * 8 + j] = make_float2(s2[j >> 1][j & 1], q2[j >> 1][j & 1]);
+        }
+        __syncthreads();
+        for (int c = t; c < a.C; c += blockDim.x) {               // column c belongs to this thread alone
+            float ss = 0.f, qq = 0.f;
+            for (int rr = 0; rr < a.R; ++rr) {
+                const float2 w = shc[(size_t)rr * a.C + c];
+                ss += w.x;
+                qq += w.y;
+            }
+            shc[c] = make_float2(ss, qq);
+        }
+        __syncthreads();
+        for (int g = t; g < a.G; g += blockDim.x) {
+            float ss = 0.f, qq = 0.f;
+            for (int cl = 0; cl < a.cpg; ++cl) {
+                const float2 w = shc[g * a.cpg + cl];
+                ss += w.x;
+                qq += w.y;
+            }
+            const unsigned long long word = ((unsigned long long)__float_as_uint(qq) << 32) | __float_as_uint(ss);
+            __hip_atomic_store(((nh_gu64*)a.gpart) + ((size_t)n * a.S + chunk) * a.G + g, word,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    clear();
+#pragma unroll
+    for (int i = 0; i < NH_OP_ROWS; ++i)
+        if (i < nv) accum(v[i]);
+    NH_STAMP(1);
+    fold_publish(sc);
+    NH_STAMP(2);
+    nh_gu32* arrived = ((nh_gu32*)a.arrived) + n;
+    if (t == 0) {
+        __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.S) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 >= (unsigned long long)a.timeout) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        *shFlag = ok;
+    }
+    __syncthreads();
+    NH_STAMP(3);
+    if (*shFlag == 0) {
+        // safety net: the peers have not all published within the bound; compute their chunks' words here
+        for (int chunk = 0; chunk < a.S; ++chunk) {
+            if (chunk == sc) continue;
+            clear();
+            if (active) {
+                const int rb = min(a.HW, (chunk + 1) * a.rows);
+                for (int row = chunk * a.rows + r; row < rb; row += a.R)
+                    accum(*reinterpret_cast<const u16x8_t*>(xp + (size_t)row * pitch));
+            }
+            fold_publish(chunk);
+        }
+    }
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {   // S x G words -> G statistics, fixed order: chunk lanes stride over the chunks, then the lanes in order
+        const int L = blockDim.x / a.G;
+        const int ls = t / a.G, g = t - ls * a.G;
+        if (ls < L) {
+            float ss = 0.f, qq = 0.f;
+            const nh_gu64* p = ((const nh_gu64*)a.gpart) + (size_t)n * a.S * a.G + g;
+            for (int c2 = ls; c2 < a.S; c2 += 8 * L) {            // eight loads in flight, summed in chunk order
+                unsigned long long word[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    word[u] = c2 + u * L < a.S ? __hip_atomic_load(p + (size_t)(c2 + u * L) * a.G, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT)
+                                               : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (c2 + u * L < a.S) {
+                        ss += __uint_as_float((unsigned)word[u]);
+                        qq += __uint_as_float((unsigned)(word[u] >> 32));
+                    }
+                }
+            }
+            shL[ls * a.G + g] = make_float2(ss, qq);
+        }
+        __syncthreads();
+        if (t < a.G) {
+            float ss = 0.f, qq = 0.f;
+            for (int l = 0; l < L; ++l) {
+                const float2 w = shL[l * a.G + t];
+                ss += w.x;
+                qq += w.y;
+            }
+            const float cnt = (float)a.cpg * (float)a.HW;
+            const float md = ss / cnt;
+            const float var = fmaxf(qq / cnt - md * md, 0.f);
+            shS[t] = make_float2(shP[t] + md, 1.0f / sqrtf(var + a.eps));
+        }
+        __syncthreads();
+    }
+    NH_STAMP(4);
+    if (!active) return;
+    float mean[8], ga[8], be[8];
+    nh_param8(a.gamma, a.adt, (size_t)cc * 8, 1.f, ga);
+    nh_param8(a.beta, a.adt, (size_t)cc * 8, 0.f, be);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float2 st = shS[(cc * 8 + j) / a.cpg];
+        mean[j] = st.x;
+        ga[j] *= st.y;
+    }
+    unsigned short* yp = reinterpret_cast<unsigned short*>(a.y) + (size_t)n * a.HW * a.C + (size_t)(row0 + r) * a.C + cc * 8;
+#pragma unroll
+    for (int i = 0; i < NH_OP_ROWS; ++i) {
+        if (i < nv) {
+            u16x8_t o;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                f32x2_t f = {Cvt<DT>::to_f32(v[i][2 * p]), Cvt<DT>::to_f32(v[i][2 * p + 1])};
+                if constexpr (HAS_ADD) {
+                    f += f32x2_t{tadd[2 * p], tadd[2 * p + 1]};
+                    f = f32x2_t{Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[0])), Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[1]))};
+                }
+                f32x2_t w = (f - f32x2_t{mean[2 * p], mean[2 * p + 1]}) * f32x2_t{ga[2 * p], ga[2 * p + 1]} +
+                            f32x2_t{be[2 * p], be[2 * p + 1]};
+                if constexpr (ACT) {
+                    const f32x2_t x2 = w * f32x2_t{-1.4426950408889634f, -1.4426950408889634f};
+                    f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])} + f32x2_t{1.0f, 1.0f};
+                    w = w * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                }
+                o[2 * p] = Cvt<DT>::from_f32(w[0]);
+                o[2 * p + 1] = Cvt<DT>::from_f32(w[1]);
+            }
+            *reinterpret_cast<u16x8_t*>(yp + (size_t)i * a.R * a.C) = o;
+        }
+    }
+#ifdef PGN_TUNING_HOOKS
+    if (a.dbg != nullptr && t == 0) {
+        a.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.dbg[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+#undef NH_STAMP
+}
+
 // workgroups aimed at per launch, minimum rows per lane: swept on MI355X (scripts/gn_exp.py): fewer, longer workgroups
 #ifdef PGN_TUNING_HOOKS
+unsigned long long* g_nh_dbg = nullptr;
 int g_nh_target_wgs = 768, g_nh_min_rows_per_lane = 24;
 #else
 constexpr int g_nh_target_wgs = 768, g_nh_min_rows_per_lane = 24;
@@ -297,10 +560,68 @@ static bool nh_geometry(int N, int C, int HW, int G, NhArgs* a) {
     return true;
 }
 
+// one-pass form: R row lanes x NH_OP_ROWS rows per lane per workgroup, at most 512 threads (two workgroups per CU at
+// <= 128 VGPRs).  False: the shape is outside the form (the three-pass form runs).
+static bool nh_geometry_onepass(int N, int C, int HW, int G, NhArgs* a, int* threads) {
+    if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return false;
+    if ((C & 7) != 0 || C / 8 > 512 || G > NH_OP_MAX_G) return false;
+    a->C = C; a->HW = HW; a->G = G; a->cpg = C / G; a->C8 = C / 8;
+    int R = 512 / a->C8;
+    if (R > HW) R = HW;
+    if (R > 64) R = 64;
+    a->R = R;
+    a->rows = NH_OP_ROWS * R;
+    a->S = (HW + a->rows - 1) / a->rows;
+    *threads = ((R * a->C8 + 63) / 64) * 64;
+    if (*threads < 64) *threads = 64;
+    if (*threads < G) return false;
+    return (long long)N * a->S <= 0x7fffffffLL;
+}
+
+static size_t nh_onepass_lds(const NhArgs& a, int threads) {
+    return ((size_t)a.R * a.C + (size_t)threads + NH_OP_MAX_G) * sizeof(float2) + NH_OP_MAX_G * sizeof(float) + 16;
+}
+
+// workspace of the one-pass form: [N] arrival counters in a block of their own (padded to 256 bytes: the per-call memset
+// zeroes exactly that block), then the [N][S][G] words
+static size_t nh_onepass_counter_bytes(int N) { return (((size_t)N * sizeof(unsigned int)) + 255) & ~(size_t)255; }
+
+static size_t nh_workspace_need(int N, int C, int HW, int G) {
+    NhArgs a;
+    if (!nh_geometry(N, C, HW, G, &a)) return 0;
+    size_t need = ((size_t)N * a.S * C + (size_t)N * G) * sizeof(float2);
+    NhArgs b;
+    int threads;
+    if (nh_geometry_onepass(N, C, HW, G, &b, &threads)) {
+        const size_t n1 = nh_onepass_counter_bytes(N) + (size_t)N * b.S * G * sizeof(unsigned long long);
+        if (n1 > need) need = n1;
+    }
+    return need;
+}
+
+// compute units of the current device (the one-pass form is only picked when a sample's workgroups fit the chip)
+static int nh_device_cus() {
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+
+static bool nh_ranges_overlap(const void* p, size_t pb, const void* q, size_t qb) {
+    const uintptr_t a0 = (uintptr_t)p, b0 = (uintptr_t)q;
+    return a0 < b0 + qb && b0 < a0 + pb;
+}
+
 }  // namespace
 
 #ifdef PGN_TUNING_HOOKS
 // measurement build only (make tuning): geometry sweep hook of scripts/gn_exp.py; absent from the shipped library
+extern "C" void pgn_groupnorm_nhwc_debug_buffer(void* p) { g_nh_dbg = (unsigned long long*)p; }
 extern "C" void pgn_groupnorm_nhwc_tuning(int target_wgs, int min_rows_per_lane) {
     g_nh_target_wgs = target_wgs;
     g_nh_min_rows_per_lane = min_rows_per_lane;
@@ -308,9 +629,7 @@ extern "C" void pgn_groupnorm_nhwc_tuning(int target_wgs, int min_rows_per_lane)
 #endif
 
 extern "C" size_t pgn_groupnorm_nhwc_workspace_bytes(int N, int C, int HW, int G) {
-    NhArgs a;
-    if (!nh_geometry(N, C, HW, G, &a)) return 0;
-    return ((size_t)N * a.S * C + (size_t)N * G) * sizeof(float2);
+    return nh_workspace_need(N, C, HW, G);
 }
 
 static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, const void* gamma, const void* beta,
@@ -334,17 +653,67 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
     if ((gamma != nullptr && (!pgn_aligned(gamma, 16) || !pgn_aligned(beta, 16))) ||
         (add_nc != nullptr && !pgn_aligned(add_nc, 16)))
         return PGN_ERR_INVALID;
-    const size_t need = ((size_t)N * a.S * C + (size_t)N * G) * sizeof(float2);
+    const size_t need = nh_workspace_need(N, C, HW, G);
     if (workspace_bytes < need) return PGN_ERR_INVALID;
     a.x = x; a.x2 = x2; a.C1 = C1; a.y = y; a.gamma = gamma; a.beta = beta; a.addnc = add_nc; a.adt = affine_dtype; a.add_dt = add_dtype;
     a.eps = eps; a.act = act;
+    a.arrived = nullptr; a.gpart = nullptr; a.timeout = 0;
+#ifdef PGN_TUNING_HOOKS
+    a.dbg = g_nh_dbg;
+#endif
+    hipStream_t s = (hipStream_t)stream;
+    const bool has_add = add_nc != nullptr;
+    {
+        // One-pass form (1R + 1W, one launch) for tensors of up to NH_OP_MAX_BYTES: there it beats the three launches
+        // (18-25 us against 28-31 us at the UNet's shapes for batches 1-4, scripts/gn_onepass_ab.py).  On larger
+        // tensors every CU is streaming, the exchange between a sample's workgroups takes 20-30 us under that load and
+        // the 368 KB a CU holds in registers cannot cover it: measured 0.70-0.87x of the three-pass form at batch 32
+        // (profiles/r02_groupnorm_onepass_ab.txt), so those keep the three passes.  Also required: a sample's S
+        // workgroups fit the chip at least twice over, x and y do not overlap.  PGN_GN_NHWC_ONEPASS=0: never; =1:
+        // whenever the shape allows (tests, measurements); PGN_GN_NHWC_ONEPASS_TIMEOUT=<ticks>: bound of the wait (0:
+        // every workgroup takes the safety net; tests).
+        NhArgs b = a;
+        int threads1 = 0;
+        const char* sw = getenv("PGN_GN_NHWC_ONEPASS");
+        bool onepass = !(sw != nullptr && sw[0] == '0') && nh_geometry_onepass(N, C, HW, G, &b, &threads1);
+        if (onepass) {
+            const int cus = nh_device_cus();
+            const long long slots = 2LL * cus;
+            const size_t es = pgn_dtype_size(dtype);
+            const size_t yb = (size_t)N * HW * C * es, x1b = (size_t)N * HW * C1 * es, x2b = (size_t)N * HW * (C - C1) * es;
+            const bool forced = sw != nullptr && sw[0] == '1';
+            onepass = cus > 0 && 2LL * b.S <= slots && nh_onepass_lds(b, threads1) <= 64 * 1024 &&
+                      (forced || yb <= NH_OP_MAX_BYTES) &&
+                      !nh_ranges_overlap(x, x1b, y, yb) && !(x2 != nullptr && nh_ranges_overlap(x2, x2b, y, yb));
+        }
+        if (onepass) {
+            const char* to = getenv("PGN_GN_NHWC_ONEPASS_TIMEOUT");
+            b.timeout = to != nullptr ? (unsigned)strtoul(to, nullptr, 10) : 200000u;   // 2 ms
+            b.arrived = (unsigned int*)workspace;
+            b.gpart = (unsigned long long*)((char*)workspace + nh_onepass_counter_bytes(N));
+            const hipError_t me = hipMemsetAsync(workspace, 0, nh_onepass_counter_bytes(N), s);
+            if (me != hipSuccess) return (int)me;
+            const dim3 grid1((unsigned)(N * b.S)), block1(threads1);
+            const size_t lds1 = nh_onepass_lds(b, threads1);
+#define PGN_NH_ONEPASS(DT)                                                                                            \
+    do {                                                                                                              \
+        if (has_add && act) hipLaunchKernelGGL((pgn_gn_nhwc_onepass_kernel<DT, true, true>), grid1, block1, lds1, s, b);       \
+        else if (has_add) hipLaunchKernelGGL((pgn_gn_nhwc_onepass_kernel<DT, true, false>), grid1, block1, lds1, s, b);        \
+        else if (act) hipLaunchKernelGGL((pgn_gn_nhwc_onepass_kernel<DT, false, true>), grid1, block1, lds1, s, b);            \
+        else hipLaunchKernelGGL((pgn_gn_nhwc_onepass_kernel<DT, false, false>), grid1, block1, lds1, s, b);                    \
+    } while (0)
+            if (dtype == PGN_BF16) PGN_NH_ONEPASS(PGN_BF16);
+            else PGN_NH_ONEPASS(PGN_F16);
+#undef PGN_NH_ONEPASS
+            PGN_LAUNCH_CHECK();
+            return PGN_OK;
+        }
+    }
     a.part = (float2*)workspace;
     a.stats = a.part + (size_t)N * a.S * C;
-    hipStream_t s = (hipStream_t)stream;
     const int threads = ((a.R * a.C8 + 63) / 64) * 64;
     const size_t lds = (size_t)a.R * C * sizeof(float2);
     const dim3 grid((unsigned)(N * a.S)), block(threads);
-    const bool has_add = add_nc != nullptr;
 #define PGN_NH_LAUNCH(DT)                                                                                            \
     do {                                                                                                             \
         if (has_add) hipLaunchKernelGGL((pgn_gn_nhwc_stats_kernel<DT, true>), grid, block, lds, s, a);               \
@@ -418,7 +787,7 @@ extern "C" int pgn_groupnorm_silu_nhwc_static(const void* x, void* y, int dtype,
     if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return PGN_ERR_INVALID;
     NhArgs a;
     if (!nh_geometry(N, C, HW, G, &a)) return PGN_ERR_UNSUPPORTED;
-    const size_t need = ((size_t)N * a.S * C + (size_t)N * G) * sizeof(float2);
+    const size_t need = nh_workspace_need(N, C, HW, G);
     if (need > (size_t)PGN_GN_STATIC_SCRATCH_BYTES) return PGN_ERR_SCRATCH;
     void* ws = nullptr;
     const int rc = nh_scratch_ptr(&ws);
