@@ -14,8 +14,28 @@ import os as _os
 # find-db ships in-tree: immediate mode reads it and picks the measured-best solver with no find at run time.  Shapes
 # that are not in the db (other batch sizes / resolutions) fall back to the heuristic.
 _db = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
-if _os.path.isdir(_db):
-    _os.environ.setdefault("MIOPEN_USER_DB_PATH", _db)
+
+
+def _private_db_copy(src: str) -> str:
+    """One process per GPU: MIOpen guards its user db with lock files next to it, and N ranks opening the same in-tree
+    files at once queue on them (a lock that times out silently drops that rank to the heuristic solvers, several
+    times slower).  Ranks of a multi-process job therefore read a private copy (a few hundred KB)."""
+    import atexit, shutil, tempfile
+    dst = tempfile.mkdtemp(prefix=f"pigeon_miopen_db_r{_os.environ.get('RANK', '0')}_")
+    shutil.copytree(src, dst, dirs_exist_ok=True)
+    atexit.register(shutil.rmtree, dst, ignore_errors=True)
+    return dst
+
+
+if _os.path.isdir(_db) and "MIOPEN_USER_DB_PATH" not in _os.environ:
+    try:
+        _multi = int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1
+    except ValueError:
+        _multi = False
+    try:
+        _os.environ["MIOPEN_USER_DB_PATH"] = _private_db_copy(_db) if _multi else _db
+    except OSError:          # no writable temporary directory: share the in-tree files
+        _os.environ["MIOPEN_USER_DB_PATH"] = _db
 _os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # if a caller turns cudnn.benchmark on: db hit or heuristic, no search
 _os.environ.setdefault("MIOPEN_LOG_LEVEL", "3")
 

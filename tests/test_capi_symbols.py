@@ -124,3 +124,24 @@ def test_build_entry_point_checks_the_header_version():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "__graft_entry__.py")).read()
     assert "PGN_VERSION" in src and not re.search(r"pgn_version\(\)\s*==\s*\d", src)
+
+
+def test_ranks_of_a_multi_process_job_read_a_private_copy_of_the_find_db():
+    """One process per GPU: every rank would otherwise open (and lock) the same in-tree MIOpen user db."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, pigeon_amd; p = os.environ['MIOPEN_USER_DB_PATH']; "
+            "print(p); print(sorted(os.listdir(p))); print(sorted(pigeon_amd.tuned_points()))")
+    outs = {}
+    for tag, extra in (("single", {}), ("rank1", {"WORLD_SIZE": "2", "RANK": "1"})):
+        env = {k: v for k, v in os.environ.items() if k not in ("MIOPEN_USER_DB_PATH", "WORLD_SIZE", "RANK")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = r.stdout.strip().splitlines()
+    in_tree = os.path.join(root, "pigeon_amd", "miopen_db")
+    assert outs["single"][0] == in_tree
+    assert outs["rank1"][0] != in_tree and "pigeon_miopen_db_r1_" in outs["rank1"][0]
+    assert outs["rank1"][1:] == outs["single"][1:]              # same files, same tuned points
+    assert not os.path.exists(outs["rank1"][0])                 # removed when the process ended
