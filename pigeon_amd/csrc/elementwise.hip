@@ -151,11 +151,22 @@ __global__ __launch_bounds__(EW_THREADS) void pgn_add_layernorm_kernel(
     // the kernel's load requests, all of them to the same twenty-odd cache lines (C = 640: 58.9 -> 75.7 us).  The
     // workgroup stages it once in LDS instead, low and high halves of a lane's 8 values in separate arrays so that the
     // 16-byte LDS reads of consecutive lanes are consecutive.
+    // gamma / beta stored like the activations (the usual case) are staged the same way, behind them in the array.
     extern __shared__ __attribute__((aligned(16))) float ln_cb[];   // [C/2] low halves, [C/2] high halves (or empty)
-    if (cb != nullptr) {                                            // workgroup-uniform
-        for (int i = threadIdx.x; i < 2 * C8; i += EW_THREADS)
-            *reinterpret_cast<f32x4_t*>(ln_cb + ((i & 1) ? 4 * C8 : 0) + 4 * (i >> 1)) =
-                *reinterpret_cast<const f32x4_t*>(cb + 4 * i);
+    const bool packed_affine = gamma != nullptr && adt == DT;
+    u16x8_t* ln_gb = reinterpret_cast<u16x8_t*>(ln_cb + (cb != nullptr ? C : 0));   // [C8] gamma, [C8] beta
+    if (cb != nullptr || packed_affine) {                           // workgroup-uniform
+        if (cb != nullptr) {
+            for (int i = threadIdx.x; i < 2 * C8; i += EW_THREADS)
+                *reinterpret_cast<f32x4_t*>(ln_cb + ((i & 1) ? 4 * C8 : 0) + 4 * (i >> 1)) =
+                    *reinterpret_cast<const f32x4_t*>(cb + 4 * i);
+        }
+        if (packed_affine) {
+            for (int i = threadIdx.x; i < C8; i += EW_THREADS) {
+                ln_gb[i] = *reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(gamma) + 8 * i);
+                ln_gb[C8 + i] = *reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(beta) + 8 * i);
+            }
+        }
         __syncthreads();
     }
     if (row0 >= M) return;   // whole wavefront leaves together, behind the only barrier
@@ -229,9 +240,9 @@ __global__ __launch_bounds__(EW_THREADS) void pgn_add_layernorm_kernel(
             if (gamma == nullptr) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { ga[j] = 1.0f; be[j] = 0.0f; }
-            } else if (adt == DT) {   // the usual case: parameters stored like the activations, one 16-byte load each
-                unpack8<DT>(*reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(gamma) + 8 * v), ga);
-                unpack8<DT>(*reinterpret_cast<const u16x8_t*>(reinterpret_cast<const unsigned short*>(beta) + 8 * v), be);
+            } else if (packed_affine) {   // the usual case: parameters stored like the activations, one 16-byte LDS read each
+                unpack8<DT>(ln_gb[v], ga);
+                unpack8<DT>(ln_gb[C8 + v], be);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -370,7 +381,8 @@ extern "C" int pgn_add_layernorm_cb(const void* x, const void* residual, void* s
     if (blocks > 0x7fffffffLL) return PGN_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks), block(EW_THREADS);
-    const size_t lds = col_bias != nullptr ? (size_t)C * sizeof(float) : 0;
+    const size_t lds = (col_bias != nullptr ? (size_t)C * sizeof(float) : 0) +
+                       (gamma != nullptr && affine_dtype == dtype ? (size_t)C * 4 : 0);
 #define PGN_LN_LAUNCH(DT, R, RES, NR)                                                                         \
     hipLaunchKernelGGL((pgn_add_layernorm_kernel<DT, R, RES, NR>), grid, block, lds, s, (const unsigned short*)x, \
                        (const unsigned short*)residual, (unsigned short*)sum_out, (unsigned short*)y, gamma,  \
