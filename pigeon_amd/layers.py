@@ -84,6 +84,39 @@ def conv2d_bias(conv: nn.Conv2d, x: torch.Tensor, residual: Optional[torch.Tenso
 SPLIT_CONCAT = os.environ.get("PGN_SPLIT_CONCAT", "1") != "0"
 
 
+# PGN_KEEP_DERIVED=0: recompute the derived bias vectors / the time embedding's SiLU in every forward (A/B switch)
+KEEP_DERIVED = os.environ.get("PGN_KEEP_DERIVED", "1") != "0"
+
+
+def derived_constant(owner, slot: str, sources, build):
+    """A tensor computed from frozen parameters (an fp32 copy of a bias, the sum of two biases, ...) kept on `owner`
+    instead of being recomputed by two to four tiny launches in every forward (at batch 1 a UNet forward is ~3 k
+    launches, and ~120 of them were these).  Keyed like BasicTransformerBlock._pending_biases: storage, dtype and
+    VERSION of every source, so an in-place update (load_state_dict, a LoRA merge) rebuilds it."""
+    if not KEEP_DERIVED:
+        with torch.no_grad():
+            return build()
+    key = tuple(None if t is None else (t.data_ptr(), t.dtype, t._version) for t in sources)
+    hit = owner.__dict__.get(slot)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, build())
+        owner.__dict__[slot] = hit
+    return hit[1]
+
+
+def silu_once(temb: torch.Tensor) -> torch.Tensor:
+    """F.silu(temb) for the resnets' time_emb_proj: every ResnetBlock2D of a forward applies it to the SAME embedding
+    (17 launches in the SDXL UNet); the first caller's result rides on the tensor object."""
+    hit = getattr(temb, "_pgn_silu", None) if KEEP_DERIVED else None
+    if hit is not None and hit[0] == temb._version:
+        return hit[1]
+    s = F.silu(temb)
+    if not (torch.is_grad_enabled() and temb.requires_grad):
+        temb._pgn_silu = (temb._version, s)
+    return s
+
+
 def _nhwc_rows(x: torch.Tensor) -> torch.Tensor:
     """[N*H*W, C] view of a channels_last activation."""
     return x.permute(0, 2, 3, 1).view(-1, x.shape[1])
@@ -113,6 +146,12 @@ class ResnetBlock2D(nn.Module):
                   and c == self.norm1.num_channels and c // self.norm1.num_groups <= 128 and c <= 8192)
         return ok
 
+    def _shortcut_bias(self, dtype):
+        """conv2's bias + the shortcut's, summed in fp32 and rounded once (one vector for pgn_bias_residual_add)."""
+        b2, bs = self.conv2.bias, self.conv_shortcut.bias
+        return derived_constant(self, f"_pgn_b2s_{dtype}", (b2, bs),
+                                lambda: (b2.detach().float() + bs.detach().float()).to(dtype))
+
     def forward(self, input_tensor, temb=None, skip=None):
         """diffusers ResnetBlock2D.forward.  Three broadcast / tensor adds never run as launches of their own:
         conv1's bias and the time-embedding projection travel as ONE per-(sample, channel) vector into norm2's
@@ -132,10 +171,11 @@ class ResnetBlock2D(nn.Module):
             x = self.norm1(input_tensor)
         t = None
         if self.time_emb_proj is not None and temb is not None:
-            t = self.time_emb_proj(F.silu(temb))   # [N, C]: its broadcast add is fused into norm2's kernel
+            t = self.time_emb_proj(silu_once(temb))   # [N, C]: its broadcast add is fused into norm2's kernel
         if t is not None and _bias_fusable(self.conv1, x):
             h = _conv_nobias(self.conv1, x)
-            t = t.float() + self.conv1.bias.float()
+            b1 = derived_constant(self, "_pgn_b1_f32", (self.conv1.bias,), lambda: self.conv1.bias.detach().float())
+            t = torch.add(t, b1)                   # = t.float() + conv1.bias.float() (type promotion), one launch
         else:
             h = conv2d_bias(self.conv1, x)
         h = self.norm2(h, add_nc=t)
@@ -151,7 +191,7 @@ class ResnetBlock2D(nn.Module):
             rows.addmm_(_nhwc_rows(input_tensor), w[:, :c1].t())
             if skip is not None:
                 rows.addmm_(_nhwc_rows(skip), w[:, c1:].t())
-            b = (self.conv2.bias.float() + self.conv_shortcut.bias.float()).to(hh.dtype)
+            b = self._shortcut_bias(hh.dtype)
             out = ops.bias_residual_add(hh, b, None)
         elif _bias_fusable(self.conv2, h):
             # both biases in one vector: shortcut(x) + b_s + conv2(h) + b_2
@@ -159,7 +199,7 @@ class ResnetBlock2D(nn.Module):
             hh = _conv_nobias(self.conv2, h)
             if hh.stride() == sc.stride() and (hh.is_contiguous(memory_format=torch.channels_last)
                                                or (hh.is_contiguous() and (hh.shape[2] * hh.shape[3]) % 8 == 0)):
-                b = (self.conv2.bias.float() + self.conv_shortcut.bias.float()).to(hh.dtype)
+                b = self._shortcut_bias(hh.dtype)
                 out = ops.bias_residual_add(hh, b, sc)
             else:
                 out = (sc + self.conv_shortcut.bias.view(1, -1, 1, 1)) + (hh + self.conv2.bias.view(1, -1, 1, 1))

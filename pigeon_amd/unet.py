@@ -22,6 +22,7 @@ import torch.nn as nn
 from . import ops
 from .attention_processor import Attention, HipAttnProcessor
 from .layers import (Downsample2D, GroupNormAct, ResnetBlock2D, TimestepEmbedding, Upsample2D, conv2d_bias,
+                     derived_constant,
                      timestep_embedding)
 
 
@@ -204,7 +205,10 @@ class Transformer2DModel(nn.Module):
             else:
                 # the last block's pending bias goes through the projection as a bias term: W (x + cb) + b
                 po = self.proj_out
-                b_eff = (po.weight.float() @ cb + (0.0 if po.bias is None else po.bias.float())).to(hidden_states.dtype)
+                dt = hidden_states.dtype
+                b_eff = derived_constant(
+                    self, f"_pgn_b_eff_{dt}", (po.weight, po.bias, cb),
+                    lambda: (po.weight.detach().float() @ cb + (0.0 if po.bias is None else po.bias.detach().float())).to(dt))
                 hidden_states = torch.nn.functional.linear(hidden_states, po.weight, b_eff)
             hidden_states = hidden_states.reshape(b, h, w, c).permute(0, 3, 1, 2)
             if not cl:

@@ -490,7 +490,7 @@ def test_fused_qkv_projection_equals_separate_projections(stack, monkeypatch):
 
 @pytest.mark.parametrize("switch", [("pigeon_amd.unet", "ACCUMULATE_ATTENTION"), ("pigeon_amd.unet", "ACCUMULATE_FF"),
                                     ("pigeon_amd.layers", "FUSE_CONV_BIAS"), ("pigeon_amd.layers", "SPLIT_CONCAT"),
-                                    ("pigeon_amd.layers", "HIP_UPSAMPLE")])
+                                    ("pigeon_amd.layers", "HIP_UPSAMPLE"), ("pigeon_amd.layers", "KEEP_DERIVED")])
 def test_host_side_restructurings_agree_with_the_plain_order(stack, monkeypatch, switch):
     # every restructuring around the library GEMMs / convolutions (INTEGRATION.md switch table) is the same real
     # arithmetic in another order: switched off, the UNet and the VAE agree with the default build to the bf16 floor

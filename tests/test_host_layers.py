@@ -67,3 +67,39 @@ def test_pending_bias_totals_follow_in_place_weight_updates():
     assert torch.allclose(blk._pending_biases(cb)[0], n1 + 0.25)
     cb += 1.0
     assert torch.allclose(blk._pending_biases(cb)[0], n1 + 1.25)
+
+
+def test_derived_constants_follow_in_place_parameter_updates_and_silu_is_computed_once():
+    # the resnets' fp32 conv1 bias, the summed conv2 + shortcut bias and Transformer2DModel's folded projection bias
+    # are kept between forwards (layers.derived_constant): same key discipline as the pending-bias totals
+    import copy
+    from pigeon_amd.layers import derived_constant, silu_once
+    torch.manual_seed(4)
+    blk = ResnetBlock2D(48, 32, temb_channels=16, groups=8).eval().requires_grad_(False)
+    b = blk._shortcut_bias(torch.bfloat16)
+    assert torch.equal(b, (blk.conv2.bias.float() + blk.conv_shortcut.bias.float()).to(torch.bfloat16))
+    assert blk._shortcut_bias(torch.bfloat16) is b                      # kept
+    assert blk._shortcut_bias(torch.float16).dtype == torch.float16     # one slot per dtype
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    sd["conv2.bias"] += 2.0
+    blk.load_state_dict(sd)                                             # in place: same storage, new version
+    nb = blk._shortcut_bias(torch.bfloat16)
+    assert nb is not b and torch.equal(nb, (blk.conv2.bias.float() + blk.conv_shortcut.bias.float()).to(torch.bfloat16))
+    assert set(blk.state_dict()) == set(sd)                             # the kept tensors are not state
+    twin = copy.deepcopy(blk)                                           # other storage: the copy rebuilds its own
+    twin.conv2.bias.add_(1.0)
+    assert torch.equal(twin._shortcut_bias(torch.bfloat16),
+                       (twin.conv2.bias.float() + twin.conv_shortcut.bias.float()).to(torch.bfloat16))
+    calls = []
+    src = torch.randn(8)
+    first = derived_constant(blk, "_t", (src, None), lambda: calls.append(1) or src * 2)
+    assert derived_constant(blk, "_t", (src, None), lambda: calls.append(1) or src * 2) is first and len(calls) == 1
+    # silu of the time embedding: once per tensor object and version
+    temb = torch.randn(2, 16)
+    s = silu_once(temb)
+    assert torch.equal(s, torch.nn.functional.silu(temb)) and silu_once(temb) is s
+    temb.mul_(2.0)
+    assert torch.equal(silu_once(temb), torch.nn.functional.silu(temb))
+    # and the promoted add the resnet uses equals the three-launch form it replaces
+    t16 = torch.randn(2, 32).bfloat16()
+    assert torch.equal(torch.add(t16, blk.conv1.bias.float()), t16.float() + blk.conv1.bias.float())
