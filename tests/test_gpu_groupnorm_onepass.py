@@ -206,3 +206,37 @@ def test_one_pass_at_the_bench_shape_is_reproducible_and_close_to_three_pass():
         m1 = ys[0].float().mean(dim=1)
         m3 = y3.float().mean(dim=1)
         assert (m1 - m3).abs().max().item() < 1e-3
+
+
+def test_one_pass_random_shapes_against_the_oracle():
+    """Thirty seeded shapes: every remainder of rows against the chunk size, 1-64 row lanes, channel counts whose
+    16-byte chunks do not fill a wavefront, 1-16 channels per group, with and without the per-sample addend."""
+    import random
+    lib = _lib.load()
+    rnd = random.Random(20241)
+    with _env(PGN_GN_NHWC_ONEPASS="1"):
+        for i in range(30):
+            G = rnd.choice([1, 2, 4, 8, 16, 32, 64])
+            cpg = rnd.choice([1, 2, 3, 4, 5, 8, 10, 16])
+            C = G * cpg
+            while C % 8:
+                C += G
+            if C > 2048:
+                C = G * 8
+            N = rnd.randint(1, 5)
+            HW = rnd.choice([1, 2, 7, 63, 64, 65, 255, 257, 1000, 1024, 1025, 3000, 4097])
+            with_add, act = rnd.random() < 0.5, rnd.randint(0, 1)
+            dtype = rnd.choice([torch.bfloat16, torch.float16])
+            x, gamma, beta, add = _inputs(N, HW, C, dtype, 500 + i, with_add)
+            dev = [t if t is None else t.to(DEV) for t in (x, gamma, beta, add)]
+            nbytes = int(lib.pgn_groupnorm_nhwc_workspace_bytes(N, C, HW, G))
+            assert nbytes > 0, (N, HW, C, G)
+            ws = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device=DEV)
+            y = torch.full_like(dev[0], float("nan"))
+            _call(lib, dev[0], y, dev[1], dev[2], dev[3], G, 1e-5, act, ws)
+            torch.cuda.synchronize()
+            want = _oracle(x, gamma, beta, add, G, 1e-5, act)
+            ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+            err = (y.cpu().float() - want.float()).abs()
+            ok = err <= ulp * want.float().abs() + 4 * ulp * 2.0 ** -7 + 1e-6
+            assert bool(ok.all()), (i, N, HW, C, G, with_add, act, dtype, err.max().item())
