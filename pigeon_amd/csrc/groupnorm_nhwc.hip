@@ -40,6 +40,7 @@ struct NhArgs {
     int rows;        // rows per chunk
     float eps;
     int act;
+    int reverse;     // apply pass: walk the workgroups from the last row chunk of the last sample to the first
     float2* part;    // [N][S][C]
     float2* stats;   // [N][G]
     // one-pass form only
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(NH_FIN_THREADS) void pgn_gn_nhwc_finalize_kernel(Nh
 
 template <int DT, bool HAS_ADD, bool ACT>
 __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArgs a) {
-    const int n = blockIdx.x / a.S, sc = blockIdx.x % a.S;
+    const unsigned bid = a.reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int n = bid / a.S, sc = bid % a.S;
     const int t = threadIdx.x;
     const int r = t / a.C8, cc = t - r * a.C8;
     if (r >= a.R) return;
@@ -535,9 +537,11 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_onepass_kernel(NhA
 // workgroups aimed at per launch, minimum rows per lane: swept on MI355X (scripts/gn_exp.py): fewer, longer workgroups
 #ifdef PGN_TUNING_HOOKS
 unsigned long long* g_nh_dbg = nullptr;
+int g_nh_reverse = 1;
 int g_nh_target_wgs = 768, g_nh_min_rows_per_lane = 24;
 #else
 constexpr int g_nh_target_wgs = 768, g_nh_min_rows_per_lane = 24;
+constexpr int g_nh_reverse = 1;
 #endif
 
 // geometry shared by the workspace query and the launch
@@ -622,6 +626,7 @@ static bool nh_ranges_overlap(const void* p, size_t pb, const void* q, size_t qb
 #ifdef PGN_TUNING_HOOKS
 // measurement build only (make tuning): geometry sweep hook of scripts/gn_exp.py; absent from the shipped library
 extern "C" void pgn_groupnorm_nhwc_debug_buffer(void* p) { g_nh_dbg = (unsigned long long*)p; }
+extern "C" void pgn_groupnorm_nhwc_reverse(int on) { g_nh_reverse = on; }
 extern "C" void pgn_groupnorm_nhwc_tuning(int target_wgs, int min_rows_per_lane) {
     g_nh_target_wgs = target_wgs;
     g_nh_min_rows_per_lane = min_rows_per_lane;
@@ -657,6 +662,13 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
     if (workspace_bytes < need) return PGN_ERR_INVALID;
     a.x = x; a.x2 = x2; a.C1 = C1; a.y = y; a.gamma = gamma; a.beta = beta; a.addnc = add_nc; a.adt = affine_dtype; a.add_dt = add_dtype;
     a.eps = eps; a.act = act;
+    // Three-pass form: the apply pass re-reads what the statistics pass read.  Tensors of up to ~170 MB are still in
+    // the 256 MiB Infinity Cache then (3.6 TB/s algorithmic); of a larger one only what was read LAST is, so its apply
+    // pass walks the tensor backwards (336-503 MB tensors: +5..8 %, scripts/gn_reverse_ab.py; smaller ones lose 0-2 %
+    // that way and keep the forward walk).  Same arithmetic per workgroup: bit-identical.  Processing the tensor in
+    // sample ranges that fit the cache, statistics and apply back to back, was measured too and is 10-24 % SLOWER
+    // (smaller launches, and the range's own output evicts the rows it has not re-read yet).
+    a.reverse = (g_nh_reverse && (size_t)N * HW * C * pgn_dtype_size(dtype) > ((size_t)200 << 20)) ? 1 : 0;
     a.arrived = nullptr; a.gpart = nullptr; a.timeout = 0;
 #ifdef PGN_TUNING_HOOKS
     a.dbg = g_nh_dbg;
