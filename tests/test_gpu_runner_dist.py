@@ -1,0 +1,154 @@
+"""The caller side (inference.py:345-458) driving the REAL pipeline on the GPU: `runner.generate_images` over a tiny
+PigeonPixelDecoder whose every op runs on the HIP kernels, first on one rank, then on two ranks.
+
+A one-GPU box has no second device for RCCL (which refuses two ranks on one device), so the two ranks share cuda:0 and
+talk over `gloo` - the rehearsal DESIGN.md section 6 describes: everything but the RCCL transport is the production
+code (rendezvous, per-rank shard, global noise drawn from the same seed and sliced, the one all-gather of latents +
+scores per outer batch, rank 0's merged files).  What must hold: the 2-rank run returns, on both
+ranks, the latents and files of the 1-rank run.  Noise rows are identical by construction; the denoised latents are not
+bit-identical because a rank's UNet batch is half as large (other GEMM tiles, other accumulation orders), so the bar is
+a FIXED batch-independence bar: the stack runs in fp16 (8x lower rounding floor than bf16, where the same comparison
+measures 0.029), worst per-image relative L2 of the final latents <= 0.006 (measured 0.0036 on MI355X), while rows
+shifted by one image - what a slicing mistake in noise, tokens or the gather would produce - measure 1.45."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+BAR = 0.006
+N_TASKS, NRS, NRI, BS, SIDE, STEPS, SEED = 5, 1, 2, 3, 128, 3, 123
+# the tiny stack of tests/test_gpu_models.py
+TINY_UNET = dict(block_out_channels=(64, 128, 128), attention_head_dim=(1, 2, 2), transformer_layers_per_block=(1, 1, 2),
+                 cross_attention_dim=2048, layers_per_block=2, sample_size=16)
+TINY_VAE = dict(block_out_channels=(32, 64), layers_per_block=1, latent_channels=4, norm_num_groups=32,
+                scaling_factor=0.13025)
+SCHED = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000,
+             steps_offset=1, clip_sample=False, set_alpha_to_one=False, timestep_spacing="leading")
+
+
+def _build_pipe():
+    from oracle import weights          # synthetic weights only: the oracle's generator, none of its arithmetic
+    from pigeon_amd.pipeline import PigeonPixelDecoder
+    from pigeon_amd.schedulers import DDIMScheduler
+    from pigeon_amd.token_decoder import HighresVQDecoder
+    from pigeon_amd.unet import UNet2DConditionModel
+    from pigeon_amd.vae import AutoencoderKL
+    unet = UNet2DConditionModel(**TINY_UNET)
+    unet.load_state_dict(weights.synth_like(unet, 11))
+    dec = HighresVQDecoder(depth=2)
+    dec.load_state_dict(weights.synth_like(dec, 123))
+    vae = AutoencoderKL(**TINY_VAE)
+    vae.load_state_dict(weights.synth_like(vae, 5))
+    return PigeonPixelDecoder(weights.synth_codebook(), dec, unet, vae, DDIMScheduler(**SCHED), "fp16", "cuda")
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(7)
+    tokens = [torch.randint(32002, 48386, (int(torch.randint(20, 200, (1,), generator=g)),), generator=g)
+              for _ in range(N_TASKS * NRS)]
+    uids = list(range(100, 100 + N_TASKS))
+    genres = [i % 3 for i in range(N_TASKS)]
+    targets = [1000 + i for i in range(N_TASKS)]
+    history = [torch.arange(5) + i for i in range(N_TASKS)]
+    labels = [torch.arange(3) + i for i in range(N_TASKS)]
+    return tokens, labels, uids, genres, targets, history
+
+
+def _scorer(images, text_features, history_features):
+    """Mean grey level of the decoded image and its task's feature: depends on which image and which task row."""
+    return torch.tensor([[float(np.asarray(im, dtype=np.float32).mean()), float(text_features[i, 0])]
+                         for i, im in enumerate(images)])
+
+
+def _run(pipe, folder, **kw):
+    tokens, labels, uids, genres, targets, history = _inputs()
+    return pipe_run(pipe, tokens, labels, uids, genres, targets, history, folder, **kw)
+
+
+def pipe_run(pipe, tokens, labels, uids, genres, targets, history, folder, **kw):
+    from pigeon_amd import runner
+    return runner.generate_images(pipe, tokens, labels, uids, genres, targets, history, num_return_sequences=NRS,
+                                  batch_size=BS, save_folder=folder, eval_name="e", num_return_images=NRI,
+                                  width=SIDE, height=SIDE, num_inference_steps=STEPS, scorer=_scorer,
+                                  text_features=torch.arange(N_TASKS, dtype=torch.float32)[:, None],
+                                  return_latents=True, **kw)
+
+
+def _rank_main(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pigeon_amd import _lib
+        pipe = _build_pipe()
+        res, sel, lat = _run(pipe, os.path.join(tmp, "w2"), rank=rank, world_size=world, seed=SEED)
+        assert "pigeon_amd/lib/libpigeon_hip.so" in open("/proc/self/maps").read() and _lib.load() is not None
+        torch.save((res, sel, lat), os.path.join(tmp, f"out_rank{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).flatten(1).norm(dim=1) / b.double().flatten(1).norm(dim=1)).max().item()
+
+
+@pytest.mark.timeout(600)
+def test_runner_on_the_real_pipeline_one_rank_then_two(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    pipe = _build_pipe()
+    n_img = N_TASKS * NRS * NRI
+    gen = torch.Generator(device="cuda").manual_seed(SEED)
+    res1, sel1, lat1 = _run(pipe, str(tmp_path / "w1"), generator=gen)
+    assert lat1.shape == (n_img, 4, SIDE // 8, SIDE // 8) and lat1.dtype == torch.float32
+    assert torch.isfinite(lat1).all()
+
+    # (a) the runner adds nothing to the path: outer batch 0 (tasks 0..2) equals a direct generate_image call on the
+    #     same tokens with the same generator state (the runner draws nothing else from it), bit for bit
+    tokens = _inputs()[0]
+    gen = torch.Generator(device="cuda").manual_seed(SEED)
+    direct = pipe.generate_image(image_tokens=[t.cuda() for t in tokens[:BS * NRS]], num_return_images=NRI, width=SIDE,
+                                 height=SIDE, num_inference_steps=STEPS, guidance_scale_for_diffusion=7.0,
+                                 generator=gen, output_type="latent")[0].float().cpu()
+    assert torch.equal(direct, lat1[:BS * NRS * NRI])
+    # files: one JPEG per image in the reference's tree, all_res / select_scores in its layout
+    jpgs = sorted(os.path.relpath(os.path.join(r, f), tmp_path / "w1") for r, _, fs in os.walk(tmp_path / "w1")
+                  for f in fs if f.endswith(".jpg"))
+    assert len(jpgs) == n_img and jpgs[0] == "dm_scale7.0/100/1000/0/0/0.jpg"
+    assert sorted(res1) == list(range(100, 100 + N_TASKS))
+
+    # (b) two ranks on the one device
+    port = _free_port()
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(tmp_path / f"out_rank{r}.pt") for r in range(2)]
+    assert torch.equal(outs[0][2], outs[1][2]) and outs[0][1] == outs[1][1]        # every rank holds the same gather
+    lat2 = outs[0][2]
+    assert lat2.shape == lat1.shape
+    worst = _rel(lat2, lat1)
+    # control: rows shifted by one image = what a slicing mistake would produce
+    wrong = _rel(torch.roll(lat2, 1, dims=0), lat1)
+    print(f"2-rank vs 1-rank final latents: worst per-image relL2 {worst:.4f} (bar {BAR}); shifted rows {wrong:.3f}")
+    assert worst <= BAR and wrong > 0.5
+    jpgs2 = sorted(os.path.relpath(os.path.join(r, f), tmp_path / "w2") for r, _, fs in os.walk(tmp_path / "w2")
+                   for f in fs if f.endswith(".jpg"))
+    assert jpgs2 == jpgs
+    assert not any(f.endswith(".npy") and ".rank" in f for f in os.listdir(tmp_path / "w2"))
+    res2 = np.load(tmp_path / "w2" / "all_res_dm_scale7.0.npy", allow_pickle=True).item()       # our own file
+    assert list(res2) == list(res1)
+    sel2 = np.load(tmp_path / "w2" / "select_scores_dm_scale7.0.npy", allow_pickle=True).item()  # our own file
+    for i, uid in enumerate(res1):
+        a, b = sel1[uid][1000 + i][i % 3], sel2[uid][1000 + i][i % 3]
+        for s in range(NRS):
+            assert a[s]["hist_score"] == b[s]["hist_score"] == [float(i)] * NRI      # the task's own feature row
+            assert np.allclose(a[s]["tgt_score"], b[s]["tgt_score"], atol=2.0)       # mean grey level, 0..255
