@@ -804,8 +804,9 @@ extern "C" int pgn_groupnorm_silu_nhwc_static(const void* x, void* y, int dtype,
     void* ws = nullptr;
     const int rc = nh_scratch_ptr(&ws);
     if (rc != PGN_OK) return rc;
-    // every workspace word the finalize / apply launches read is written by the launch before it on the same stream:
-    // nothing has to start at zero, whatever the previous call left behind
+    // three-launch form: every workspace word the finalize / apply launches read is written by the launch before it
+    // on the same stream; one-launch form: nh_run zeroes the arrival counters with hipMemsetAsync on the same stream
+    // and every partial-sum word is published before it is read.  So nothing depends on what the previous call left.
     return nh_run(x, C, nullptr, y, dtype, gamma, beta, affine_dtype, add_nc, add_dtype, N, C, HW, G, eps, act, ws,
                   (size_t)PGN_GN_STATIC_SCRATCH_BYTES, stream);
 }

@@ -36,8 +36,11 @@ def _run(lib, static, x, gamma, beta, add, G, eps, act):
 def test_static_scratch_groupnorm_equals_the_workspace_entry_point():
     lib = _lib.load()
     g = torch.Generator().manual_seed(5)
-    # first a shape with many row chunks (large workspace footprint), then a smaller one that reuses the same array
-    for (N, HW, C, G, with_add, act) in ((4, 4096, 640, 32, True, 1), (2, 320, 64, 32, False, 0)):
+    # first a tensor above 32 MiB (three launches: statistics, finalize, apply exchange [N][S][C] partial sums through
+    # the array), then two smaller ones that take the one-launch form (arrival counters + [N][S][G] words in the same
+    # array, over whatever the call before left there)
+    for (N, HW, C, G, with_add, act) in ((8, 4096, 640, 32, True, 1), (4, 4096, 640, 32, True, 1),
+                                         (2, 320, 64, 32, False, 0)):
         x = (torch.randn(N, HW, C, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
         gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(torch.bfloat16)
         beta = (0.1 * torch.randn(C, generator=g)).to(torch.bfloat16)
