@@ -140,6 +140,62 @@ def cpu_baseline(pipe, tokens, height, width, n_steps, guidance, threads, timed_
     return 1.0 / total, t_embed, t_steps, threads
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, script=None, poll_s=0.2, env=None):
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE): start N fresh rank processes of this script, one
+    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, as torch.distributed.run
+    sets them), relay rank 0's stdout (the one JSON line), send the other ranks' stdout to stderr, and return the first
+    non-zero exit code of any rank (its siblings are then stopped by PID: a rank that died would leave them waiting in
+    the rendezvous).  The parent never touches the GPU: nothing is re-executed after a HIP call.
+    The reference's own multi-GPU switch is the broken WORLD_SIZE branch of Pigeon/inference.py:120-124."""
+    import subprocess
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("MASTER_PORT", str(free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    base["WORLD_SIZE"] = base["LOCAL_WORLD_SIZE"] = str(n)
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, "-u", script or os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), text=r == 0))
+
+    def relay():   # line by line, so the driver sees the JSON line as soon as rank 0 prints it
+        for ln in procs[0].stdout:
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        time.sleep(poll_s)
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    rc = code if code > 0 else 128 - code
+                    print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+    for r in live:                      # only after a failure: exact PIDs of our own children
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+            procs[r].wait()
+    t.join(timeout=10)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,10 +226,13 @@ def main():
         if getattr(args, k) is None:
             setattr(args, k, preset[k])
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (before any GPU call or torch.cuda query)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -189,6 +248,9 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(args.dist_backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        world = dist.get_world_size()       # n_gpus of the line = ranks that really joined
 
     t_start = time.perf_counter()
     state = {"phase": "build"}
@@ -211,8 +273,13 @@ def main():
                              "latents for the all-gather)")
         pipe.enable_hip_graph(True)
     n_seq = args.batch // args.num_return_images
-    tokens = [t.to(device) for t in synthetic.synthetic_tokens(n_seq, seed=123 + rank)]
-    gen = torch.Generator(device=device).manual_seed(123 + rank)
+    # The global-noise contract of runner.generate_images: the N ranks work on ONE job of N x batch
+    # images - one token list, one generator seeded alike on every rank that draws the job's whole noise tensor per
+    # step; a rank takes its contiguous rows of both.  The images are those of the same job on one GPU (rank 0's rows:
+    # bit for bit those of the N = 1 bench run, same batch shape, same kernels).
+    tokens = [t.to(device) for t in synthetic.synthetic_tokens(n_seq * world, seed=123)[rank * n_seq:(rank + 1) * n_seq]]
+    gen = torch.Generator(device=device).manual_seed(123)
+    lat_shape = (args.batch * world, pipe.unet.config.in_channels, args.height // 8, args.width // 8)
     timer = LaunchTimer()
     ops.set_launch_timer(timer)
 
@@ -222,10 +289,11 @@ def main():
         mark = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
         last["mark"] = mark
         mark[0].record()
+        noise = runner.global_noise(lat_shape, 123, device, gen)[rank * args.batch:(rank + 1) * args.batch]
         images, _, _ = pipe.generate_image(image_tokens=tokens, num_return_images=args.num_return_images,
                                            width=args.width, height=args.height,
                                            num_inference_steps=args.denoise_steps,
-                                           guidance_scale_for_diffusion=args.guidance, generator=gen,
+                                           guidance_scale_for_diffusion=args.guidance, latents=noise,
                                            output_type="uint8", callback=None if args.hip_graph else keep_latents)
         host = images.cpu()   # device -> host boundary (lavit_for_pigeon.py:782), uint8 instead of fp32
         if world > 1:         # the path's one exchange step: collect final latents from every rank
@@ -333,7 +401,14 @@ def main():
                                    "end to end incl. VAE decode and uint8 copy to host",
                        "baseline_config": args.config, "batch_per_gpu": args.batch,
                        "num_return_images": args.num_return_images, "height": args.height, "width": args.width,
-                       "denoise_steps": args.denoise_steps, "parallelism": f"sample-sharded dp{world}"},
+                       "denoise_steps": args.denoise_steps, "parallelism": f"sample-sharded dp{world}",
+                       "noise": "one generator (seed 123) draws the job's global noise on every rank, rows sliced by rank",
+                       "dist_backend": args.dist_backend if world > 1 else None,
+                       # the version-keyed tuning tables were accepted by the running libraries (else the hipBLASLt /
+                       # MIOpen heuristics ran and the constructor has warned)
+                       "tuned_gemms": bool(pipe.tuned_gemms), "miopen_db_hit": bool(pipe.miopen_db_hit)},
+            # ranks that joined the RCCL (backend "nccl") process group; 0 for a one-rank run or a gloo rehearsal
+            "rccl_ranks": world if (world > 1 and args.dist_backend == "nccl") else 0,
             # embeds + denoising loop only (no VAE decode / uint8 copy), this rank's GPU time per step
             "loop_only": {"images_per_sec_per_gpu": args.batch / (loop_ms * 1e-3) if loop_ms > 0 else None,
                           "ms_per_step": loop_ms if loop_ms > 0 else None},

@@ -71,20 +71,119 @@ def warn_if_untuned(unet_batch: int, latent_h: int, latent_w: int):
                       f"{key[1] * 8} --width {key[2] * 8}` has been run once on this machine", stacklevel=3)
 
 
-def enable_tuned_gemms(path=None):
+def _csv_validators(path):
+    """The `Validator,NAME,VALUE` rows of a TunableOp table: the library builds it was tuned against."""
+    out = {}
+    with open(path) as fh:
+        for ln in fh:
+            parts = ln.rstrip("\n").split(",", 2)
+            if len(parts) == 3 and parts[0] == "Validator":
+                out[parts[1]] = parts[2]
+    return out
+
+
+def gemm_table_mismatches(path, running=None):
+    """Validator rows of the table at `path` that differ from the running libraries ({name: value}, default: what
+    torch's TunableOp reports on this GPU).  TunableOp refuses the WHOLE table on any mismatch (read_file -> False) and
+    every Linear then runs the library heuristic: ['NAME: table X, running Y', ...] says which row did it."""
+    if running is None:
+        import torch.cuda.tunable as tn
+        running = dict(tn.get_validators())
+    table = _csv_validators(path)
+    return [f"{k}: table {v!r}, running {running.get(k)!r}" for k, v in table.items() if running.get(k) != v]
+
+
+_gemm_tables = {}     # path -> loaded?  (a second PigeonPixelDecoder in the process reuses the first one's answer)
+
+
+def enable_tuned_gemms(path=None, _tn=None):
     """Turn torch's TunableOp on in LOOK-UP mode with the GEMM table shipped in-tree (pigeon_amd/tunableop/, produced
     by scripts/tune_gemm.py): Linear layers whose (M, N, K) are in the table run the measured-fastest hipBLASLt /
     rocBLAS solution, every other shape keeps the library heuristic; nothing is tuned at run time.  Returns True when
-    the table was loaded.  PIGEON_TUNABLEOP=0 disables it."""
+    the table was loaded, and WARNS when it was not: the table is keyed on the torch / hipBLASLt / rocBLAS builds it was
+    tuned with (its Validator rows) and is dropped whole on any other build (library kernels).
+    PIGEON_TUNABLEOP=0 disables it (no warning: the caller asked)."""
     if _os.environ.get("PIGEON_TUNABLEOP", "1") == "0":
         return False
     path = path or _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tunableop", "gfx950_bf16.csv")
+    if path in _gemm_tables:
+        return _gemm_tables[path]
+    import warnings
     if not _os.path.exists(path):
+        warnings.warn(f"pigeon_amd: no GEMM table at {path}; Linear layers run the hipBLASLt heuristic "
+                      "(scripts/tune_gemm.py writes one)", stacklevel=3)
         return False
-    import torch.cuda.tunable as tn
-    if tn.is_enabled():          # the caller manages TunableOp itself
+    if _tn is None:
+        import torch.cuda.tunable as _tn
+    if _tn.is_enabled():          # the caller manages TunableOp itself
         return False
-    tn.enable(True)
-    tn.tuning_enable(False)
-    tn.record_untuned_enable(False)
-    return bool(tn.read_file(path))
+    _tn.enable(True)
+    _tn.tuning_enable(False)
+    _tn.record_untuned_enable(False)
+    ok = bool(_tn.read_file(path))
+    if not ok:
+        try:
+            why = gemm_table_mismatches(path, dict(_tn.get_validators()))
+        except Exception as e:   # noqa: BLE001 - the warning must not depend on the diagnosis
+            why = [f"(validators unavailable: {e})"]
+        warnings.warn(f"pigeon_amd: torch's TunableOp refused the shipped GEMM table {path}: "
+                      f"{'; '.join(why) or 'no Validator row differs (file unreadable?)'}.  Every Linear layer of the "
+                      "UNet now runs the hipBLASLt heuristic (UNet forward ~5 % slower at batch 16, more at small "
+                      "batches); re-tune on this software stack with `python scripts/tune_gemm.py --unet-only`.",
+                      stacklevel=3)
+    _gemm_tables[path] = ok
+    return ok
+
+
+def _running_miopen():
+    """What MIOpen's user find-db file name is made of on this process' GPU 0: arch, CU count, MIOpen version, build id.
+    The build id is not exposed by MIOpen's API; torch's wheel builds MIOpen and hipBLASLt from one rocm-libraries
+    commit, whose id hipBLASLt's TunableOp validator carries, so it is read from there (None if that fails: the check
+    then matches on arch / CUs / version only)."""
+    import torch
+    prop = torch.cuda.get_device_properties(0)
+    v = int(torch.backends.cudnn.version() or 0)
+    tweak = None
+    try:
+        import torch.cuda.tunable as tn
+        hv = dict(tn.get_validators()).get("HIPBLASLT_VERSION", "")
+        tweak = hv.split("-", 1)[1] if "-" in hv else None
+    except Exception:   # noqa: BLE001
+        pass
+    return {"arch": prop.gcnArchName.split(":")[0], "cus": int(prop.multi_processor_count),
+            "version": (v // 1000000, (v // 1000) % 1000, v % 1000), "build": tweak}
+
+
+def miopen_db_status(running=None, db_dir=None):
+    """Does a find-db of the RUNNING MIOpen build exist under MIOPEN_USER_DB_PATH?  MIOpen names the file
+    `<arch><CUs in hex>.HIP.<major>_<minor>_<patch>_<build id>.ufdb.txt` and silently ignores every other file, after
+    which the immediate-mode heuristic picks 3-6x slower solvers for the SDXL 3x3 convolutions (82 % of a batch-4 run,
+    profiles/r01_batch4_untuned_kernel_stats_top.txt).  -> {"hit", "expected", "found"}."""
+    import fnmatch
+    running = running or _running_miopen()
+    db_dir = db_dir or _os.environ.get("MIOPEN_USER_DB_PATH", _db)
+    maj, mnr, pat = running["version"]
+    expected = f"{running['arch']}{running['cus']:x}.HIP.{maj}_{mnr}_{pat}_{running.get('build') or '*'}.ufdb.txt"
+    try:
+        found = sorted(f for f in _os.listdir(db_dir) if f.endswith(".ufdb.txt"))
+    except OSError:
+        found = []
+    return {"hit": any(fnmatch.fnmatchcase(f, expected) for f in found), "expected": expected, "found": found,
+            "dir": db_dir}
+
+
+_miopen_warned = False
+
+
+def warn_if_miopen_db_missed(running=None, db_dir=None):
+    """Called at PigeonPixelDecoder construction; warns once per process.  Returns the `hit` flag."""
+    global _miopen_warned
+    st = miopen_db_status(running, db_dir)
+    if not st["hit"] and not _miopen_warned:
+        _miopen_warned = True
+        import warnings
+        warnings.warn(f"pigeon_amd: no MIOpen find-db for this MIOpen build under {st['dir']} (expected "
+                      f"{st['expected']}, found {st['found'] or 'nothing'}): MIOpen ignores the shipped db and its "
+                      "immediate-mode heuristic picks solvers that run the UNet's 3x3 convolutions several times "
+                      "slower.  Run `python scripts/tune_miopen.py` once on this software stack.", stacklevel=3)
+    return st["hit"]

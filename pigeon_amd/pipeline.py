@@ -80,8 +80,11 @@ class PigeonPixelDecoder:
                 raise ValueError("pixel_decoding='lowres' needs the `uncond_embeddings` buffer "
                                  "(pixel_decoding/uncond_embeddings.bin, lavit_for_pigeon.py:168)")
             self.uncond_embeddings = uncond_embeddings.detach().to(self.device)
-        from . import enable_tuned_gemms
+        # version-keyed tuning artefacts (library kernels): both calls WARN when the running library
+        # builds do not match what ships in-tree; the flags go into bench.py's line
+        from . import enable_tuned_gemms, warn_if_miopen_db_missed
         self.tuned_gemms = enable_tuned_gemms()
+        self.miopen_db_hit = warn_if_miopen_db_missed()
         if channels_last:
             for m in (self.unet, self.vae):
                 if m is not None and hasattr(m, "enable_channels_last"):
