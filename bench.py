@@ -166,10 +166,11 @@ def launch_ranks(n, argv, script=None, poll_s=0.2, env=None):
         procs.append(subprocess.Popen([sys.executable, "-u", script or os.path.abspath(__file__)] + list(argv), env=e,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), text=r == 0))
 
-    def relay():   # line by line, so the driver sees the JSON line as soon as rank 0 prints it
+    def relay():   # line by line; only rank 0's JSON line goes to stdout (gloo / RCCL banners land there too)
         for ln in procs[0].stdout:
-            sys.stdout.write(ln)
-            sys.stdout.flush()
+            out = sys.stdout if ln.lstrip().startswith("{") else sys.stderr
+            out.write(ln)
+            out.flush()
 
     t = threading.Thread(target=relay, daemon=True)
     t.start()

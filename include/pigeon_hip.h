@@ -13,7 +13,8 @@
  *     (a hipStream_t passed as void*; NULL = the legacy default stream);
  *   - return value: 0 = ok, <0 = PGN_ERR_* (argument / shape refused before any
  *     launch), >0 = a hipError_t from the launch;
- *   - re-entrant per stream, no global state (except the opt-in profiler ring);
+ *   - re-entrant per stream; no process-wide switches (no environment variable is read), no mutable global
+ *     state except pgn_groupnorm_silu_nhwc_static's per-device scratch array, which its comment describes;
  *   - bf16 / f16 tensors are passed as raw 16-bit storage.
  */
 #ifndef PIGEON_HIP_H
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PGN_VERSION 110 /* 0.1.1: + pgn_token_embed, pgn_attention_causal_fwd, pgn_groupnorm_silu_nhwc_static (additions only) */
+#define PGN_VERSION 111 /* 0.1.2: the channels-last GroupNorm entries take their choice of form as bits of `act` (the library reads no environment); 0.1.1: + pgn_token_embed, pgn_attention_causal_fwd, pgn_groupnorm_silu_nhwc_static */
 
 #define PGN_OK 0
 #define PGN_ERR_INVALID (-1)     /* null pointer, non-positive size, bad enum, misalignment */
@@ -174,12 +175,18 @@ int pgn_groupnorm_silu_ex(const void* x, int x_dtype, void* y, int y_dtype, cons
  * memset that reads and writes the tensor once: each workgroup keeps its rows in registers and the workgroups of a
  * sample exchange per-group partial sums inside the launch (agent-scope hand-off, bounded wait with a recompute safety
  * net: no dependence on dispatch order).  Both forms are deterministic (run-to-run bit-identical, no float atomics);
- * they differ from each other in the last bit of some outputs (two summation orders).  Environment, read on every
- * call: PGN_GN_NHWC_ONEPASS=0 keeps the three launches for every shape, =1 takes the one-launch form wherever the
- * shape allows (it is slower than three passes on large tensors: DESIGN.md section 4).
+ * they differ from each other in the last bit of some outputs (two summation orders).  `act` is a bit set: bit 0
+ * PGN_GN_ACT_SILU, and the caller's choice of form - PGN_GN_ONEPASS_NEVER keeps the three launches for every shape,
+ * PGN_GN_ONEPASS_ALWAYS takes the one-launch form wherever the shape allows (it is slower than three passes on large
+ * tensors: DESIGN.md section 4), PGN_GN_ONEPASS_NO_WAIT sets its wait bound to zero so that every workgroup takes the
+ * recompute safety net (tests); neither NEVER nor ALWAYS: the 32 MiB rule.  act = 0 / 1 mean what they always meant.
  * The workspace (pgn_groupnorm_nhwc_workspace_bytes, 8-byte aligned, contents irrelevant) is mandatory and must not be
  * shared by calls that may run concurrently.
  * bf16 / f16, C % 8 == 0, C <= 8192, C / G <= 128.  Algorithmic bytes as pgn_groupnorm_silu. */
+#define PGN_GN_ACT_SILU 1
+#define PGN_GN_ONEPASS_NEVER 2
+#define PGN_GN_ONEPASS_ALWAYS 4
+#define PGN_GN_ONEPASS_NO_WAIT 8
 size_t pgn_groupnorm_nhwc_workspace_bytes(int N, int C, int HW, int G);
 int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const void* gamma, const void* beta, int affine_dtype,
                             const void* add_nc, int add_dtype, int N, int C, int HW, int G, float eps, int act,
@@ -204,8 +211,10 @@ int pgn_groupnorm_silu_nhwc_cat(const void* x1, int C1, const void* x2, int C2, 
  * until the process ends) instead of caller memory, and the call path contains no hipMalloc / hipFree / allocating
  * library routine.  The first call on a device resolves that device's copy of the array (hipGetSymbolAddress; make
  * that call outside graph capture).  Shapes whose workspace (pgn_groupnorm_nhwc_workspace_bytes) exceeds
- * PGN_GN_STATIC_SCRATCH_BYTES return PGN_ERR_SCRATCH before any launch (the workspace is about 768 * C * 8
- * bytes whatever the batch: every shape with C <= 2560, i.e. the whole SDXL UNet and the VAE, fits).  All calls on one GPU share the array: calls that overlap on one GPU (two streams, two
+ * PGN_GN_STATIC_SCRATCH_BYTES return PGN_ERR_SCRATCH before any launch (for N <= 768 the workspace is about
+ * 768 * C * 8 bytes whatever the batch: every shape with C <= 2560, i.e. the whole SDXL UNet and the VAE, fits; beyond
+ * 768 samples it is N * C * 8 and grows with N).  `stream` must belong to the CURRENT device (the scratch array is
+ * resolved for the current device; a stream of another GPU is refused with PGN_ERR_INVALID).  All calls on one GPU share the array: calls that overlap on one GPU (two streams, two
  * threads) race — serialise them on one stream.  Nothing in it has to start at zero. */
 #define PGN_GN_STATIC_SCRATCH_BYTES (16u << 20)
 int pgn_groupnorm_silu_nhwc_static(const void* x, void* y, int dtype, const void* gamma, const void* beta,
@@ -240,6 +249,14 @@ int pgn_attention_fwd(const void* q, const void* k, const void* v, void* out, in
                       int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn,
                       int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn,
                       int64_t o_sh, const float* key_bias, int64_t bias_sb, float scale, void* stream);
+
+/* Which kernel class pgn_attention_fwd launches for a shape (host arithmetic, no launch): the 64-rows-per-wave ring
+ * kernel (head dim 64, no key bias, >= 256 keys, enough workgroups to fill the chip: DESIGN.md section 5) or the
+ * 32-rows-per-wave kernel.  No counterpart in the reference; it exists so that callers that time launches per kernel
+ * (bench.py's `roofline` / `kernels`) label them by the library's own rule instead of a copy of it. */
+#define PGN_ATT_KERNEL_ROWS32 0
+#define PGN_ATT_KERNEL_RING64 1
+int pgn_attention_kernel_class(int B, int H, int Nq, int Nk, int D, int has_key_bias);
 
 /* ---------------------------------------------------------------------------------------------
  * Causal multi-head self-attention over a short sequence: out[i] = softmax_{j <= i}(q_i . k_j * scale) v_j.

@@ -45,6 +45,7 @@ SIGNATURES = {
     "pgn_add_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _vp]),
     "pgn_add_layernorm_cb": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _f, _vp]),
     "pgn_image_to_uint8": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "pgn_attention_kernel_class": (_i, [_i, _i, _i, _i, _i, _i]),
     "pgn_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [_i64] * 12 + [_vp, _i64, _f, _vp]),
     "pgn_attention_causal_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_i64] * 12 + [_f, _vp]),
 }

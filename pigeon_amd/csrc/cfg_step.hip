@@ -1,6 +1,6 @@
 // Fused CFG combine + scheduler step kernels (see include/pigeon_hip.h).
 // Reference: Pigeon/models/lavit_for_pigeon.py:747-748,760-764 and diffusers 0.27.2
-// DDIMScheduler.step / EulerDiscreteScheduler.step (third-party, restated in oracle/schedulers.py).
+// DDIMScheduler.step / EulerDiscreteScheduler.step (third-party, restated in oracle/pipeline_ref.py: DDIMRef / EulerRef, and oracle/ops_ref.py: cfg_ddim_step_ref / cfg_euler_step_ref).
 //
 // HBM-bound elementwise: one read of eps_u, eps_t, x and one write of x' per element (12 B with bf16
 // eps + fp32 latents).  4 elements per lane per access (8-byte bf16x4 / 16-byte float4), grid-stride.

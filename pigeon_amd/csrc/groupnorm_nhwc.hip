@@ -648,7 +648,12 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
     if ((gamma == nullptr) != (beta == nullptr)) return PGN_ERR_INVALID;
     if (gamma != nullptr && pgn_dtype_size(affine_dtype) == 0) return PGN_ERR_INVALID;
     if (add_nc != nullptr && pgn_dtype_size(add_dtype) == 0) return PGN_ERR_INVALID;
-    if ((act != 0 && act != 1) || !(eps >= 0.f)) return PGN_ERR_INVALID;
+    // `act`: bit 0 = SiLU, bits 1-3 = the caller's choice of form (PGN_GN_ONEPASS_*); NEVER and ALWAYS exclude each other
+    if ((act & ~(PGN_GN_ACT_SILU | PGN_GN_ONEPASS_NEVER | PGN_GN_ONEPASS_ALWAYS | PGN_GN_ONEPASS_NO_WAIT)) != 0 ||
+        ((act & PGN_GN_ONEPASS_NEVER) && (act & PGN_GN_ONEPASS_ALWAYS)) || !(eps >= 0.f))
+        return PGN_ERR_INVALID;
+    const int form = act;
+    act &= PGN_GN_ACT_SILU;
     if (dtype != PGN_BF16 && dtype != PGN_F16) return PGN_ERR_UNSUPPORTED;
     NhArgs a;
     if (!nh_geometry(N, C, HW, G, &a)) return PGN_ERR_UNSUPPORTED;
@@ -681,26 +686,25 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
         // tensors every CU is streaming, the exchange between a sample's workgroups takes 20-30 us under that load and
         // the 368 KB a CU holds in registers cannot cover it: measured 0.70-0.87x of the three-pass form at batch 32
         // (profiles/r02_groupnorm_onepass_ab.txt), so those keep the three passes.  Also required: a sample's S
-        // workgroups fit the chip at least twice over, x and y do not overlap.  PGN_GN_NHWC_ONEPASS=0: never; =1:
-        // whenever the shape allows (tests, measurements); PGN_GN_NHWC_ONEPASS_TIMEOUT=<ticks>: bound of the wait (0:
-        // every workgroup takes the safety net; tests).
+        // workgroups fit the chip at least twice over, x and y do not overlap.  The caller may override the size rule
+        // through `act`: PGN_GN_ONEPASS_NEVER, PGN_GN_ONEPASS_ALWAYS (whenever the shape allows: tests, measurements),
+        // PGN_GN_ONEPASS_NO_WAIT (wait bound 0: every workgroup takes the safety net; tests).  No environment is read
+        // in here: the library has no process-wide switches (pigeon_amd/ops.py maps its own onto these bits).
         NhArgs b = a;
         int threads1 = 0;
-        const char* sw = getenv("PGN_GN_NHWC_ONEPASS");
-        bool onepass = !(sw != nullptr && sw[0] == '0') && nh_geometry_onepass(N, C, HW, G, &b, &threads1);
+        bool onepass = !(form & PGN_GN_ONEPASS_NEVER) && nh_geometry_onepass(N, C, HW, G, &b, &threads1);
         if (onepass) {
             const int cus = nh_device_cus();
             const long long slots = 2LL * cus;
             const size_t es = pgn_dtype_size(dtype);
             const size_t yb = (size_t)N * HW * C * es, x1b = (size_t)N * HW * C1 * es, x2b = (size_t)N * HW * (C - C1) * es;
-            const bool forced = sw != nullptr && sw[0] == '1';
+            const bool forced = (form & PGN_GN_ONEPASS_ALWAYS) != 0;
             onepass = cus > 0 && 2LL * b.S <= slots && nh_onepass_lds(b, threads1) <= 64 * 1024 &&
                       (forced || yb <= NH_OP_MAX_BYTES) &&
                       !nh_ranges_overlap(x, x1b, y, yb) && !(x2 != nullptr && nh_ranges_overlap(x2, x2b, y, yb));
         }
         if (onepass) {
-            const char* to = getenv("PGN_GN_NHWC_ONEPASS_TIMEOUT");
-            b.timeout = to != nullptr ? (unsigned)strtoul(to, nullptr, 10) : 200000u;   // 2 ms
+            b.timeout = (form & PGN_GN_ONEPASS_NO_WAIT) ? 0u : 200000u;   // 2 ms of 100 MHz ticks
             b.arrived = (unsigned int*)workspace;
             b.gpart = (unsigned long long*)((char*)workspace + nh_onepass_counter_bytes(N));
             const hipError_t me = hipMemsetAsync(workspace, 0, nh_onepass_counter_bytes(N), s);
@@ -804,6 +808,12 @@ extern "C" int pgn_groupnorm_silu_nhwc_static(const void* x, void* y, int dtype,
     void* ws = nullptr;
     const int rc = nh_scratch_ptr(&ws);
     if (rc != PGN_OK) return rc;
+    // the array was resolved for the CURRENT device: a stream of another GPU would hand its kernels the wrong copy
+    if (stream != nullptr) {
+        int cur = -1, sdev = -1;
+        if (hipGetDevice(&cur) != hipSuccess) return PGN_ERR_INVALID;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && sdev != cur) return PGN_ERR_INVALID;
+    }
     // three-launch form: every workspace word the finalize / apply launches read is written by the launch before it
     // on the same stream; one-launch form: nh_run zeroes the arrival counters with hipMemsetAsync on the same stream
     // and every partial-sum word is published before it is read.  So nothing depends on what the previous call left.

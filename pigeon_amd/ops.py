@@ -342,6 +342,22 @@ def group_norm_silu_cat(x1: torch.Tensor, x2: torch.Tensor, num_groups: int, wei
     return _group_norm_silu_nhwc(x1, num_groups, weight, bias, eps, silu, None, x2=x2)
 
 
+def _gn_nhwc_act(silu: bool) -> int:
+    """`act` of the channels-last GroupNorm entries: bit 0 SiLU + the choice of form (include/pigeon_hip.h,
+    PGN_GN_ONEPASS_*).  The library reads no environment; the two switches tests and measurement scripts flip inside a
+    process are read HERE, per call: PGN_GN_NHWC_ONEPASS=0 never / =1 whenever the shape allows,
+    PGN_GN_NHWC_ONEPASS_TIMEOUT=0 zero wait bound (every workgroup takes the recompute safety net)."""
+    act = 1 if silu else 0
+    sw = os.environ.get("PGN_GN_NHWC_ONEPASS", "")
+    if sw[:1] == "0":
+        act |= 2
+    elif sw[:1] == "1":
+        act |= 4
+    if os.environ.get("PGN_GN_NHWC_ONEPASS_TIMEOUT", "").strip() == "0":
+        act |= 8
+    return act
+
+
 def _group_norm_silu_nhwc(x, num_groups, weight, bias, eps, silu, add_nc, x2=None):
     """channels_last input -> channels_last output through pgn_groupnorm_silu_nhwc (no layout change, no copy)."""
     lib = _lib.load()
@@ -368,16 +384,17 @@ def _group_norm_silu_nhwc(x, num_groups, weight, bias, eps, silu, add_nc, x2=Non
         y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     ws_bytes = int(lib.pgn_groupnorm_nhwc_workspace_bytes(N, C, HW, int(num_groups)))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=x.device)
+    act = _gn_nhwc_act(silu)
 
     def run():
         if x2 is None:
             rc = lib.pgn_groupnorm_silu_nhwc(_ptr(x), _ptr(y), _dt(x), _ptr(weight), _ptr(bias), adt, _ptr(add_nc),
-                                             add_dt, N, C, HW, int(num_groups), float(eps), 1 if silu else 0, _ptr(ws),
+                                             add_dt, N, C, HW, int(num_groups), float(eps), act, _ptr(ws),
                                              ws_bytes, _stream())
         else:
             rc = lib.pgn_groupnorm_silu_nhwc_cat(_ptr(x), C1, _ptr(x2), C - C1, _ptr(y), _dt(x), _ptr(weight),
                                                  _ptr(bias), adt, _ptr(add_nc), add_dt, N, HW, int(num_groups),
-                                                 float(eps), 1 if silu else 0, _ptr(ws), ws_bytes, _stream())
+                                                 float(eps), act, _ptr(ws), ws_bytes, _stream())
         _lib.check(rc, "pgn_groupnorm_silu_nhwc")
 
     _launch("groupnorm_silu" if silu else "groupnorm", float(2 * y.numel() * y.element_size()), run)
@@ -652,9 +669,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     # bias and with >= 16 key tiles goes to the 64-rows-per-wave LDS-DMA kernel
     if D != 64:
         kind = f"attention_d{D}"
-    elif (key_bias is None and Nq >= 512 and B * heads * ((Nq + 255) // 256) >= 1024
-          and (Nk >= 1024 or (Nk >= 256 and Nk % 64 == 0))):
-        kind = "attention_w64"
+    elif lib.pgn_attention_kernel_class(B, heads, Nq, Nk, D, 0 if key_bias is None else 1) == 1:
+        kind = "attention_w64"      # the library's own rule (PGN_ATT_KERNEL_RING64): the 64-rows-per-wave ring kernel
     else:
         kind = "attention"
     _launch(kind, work, run)

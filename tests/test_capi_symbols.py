@@ -37,13 +37,37 @@ def test_library_exports_nothing_but_the_declared_symbols():
     assert exported == _declared()
 
 
+def test_library_reads_no_environment():
+    """include/pigeon_hip.h: "no process-wide switches (no environment variable is read)".  getenv / secure_getenv
+    would show up among the undefined (imported) dynamic symbols."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out, [ln for ln in out.splitlines() if "getenv" in ln]
+
+
+def test_attention_kernel_class_on_the_sdxl_shape_table():
+    """ops.attention labels a launch by asking the library (pgn_attention_kernel_class), not by a copy of its rule:
+    the SDXL shapes at batch 16 (UNet batch 32) all take the 64-row ring kernel, incl. the ragged 1216x832 ones; small
+    launches, a key bias, short key loops and other head dims take the 32-row kernel."""
+    lib = _lib.load()
+    ring = lambda B, H, Nq, Nk, D=64, bias=0: lib.pgn_attention_kernel_class(B, H, Nq, Nk, D, bias)
+    for B, H, Nq, Nk in ((32, 10, 4096, 4096), (32, 20, 1024, 1024), (16, 10, 4096, 256), (16, 20, 1024, 256),
+                         (16, 10, 3952, 3952), (16, 20, 988, 988), (4, 10, 16384, 16384)):
+        assert ring(B, H, Nq, Nk) == 1, (B, H, Nq, Nk)
+    assert ring(2, 10, 4096, 4096) == 0            # batch 1: 320 workgroups of 256 rows leave the chip half empty
+    assert ring(8, 20, 988, 256) == 0              # 640 workgroups = 1.25 rounds: the 128-row workgroups fill better
+    assert ring(6, 10, 4096, 4096) == 1            # batch 3: 960 workgroups fill it (the fill rule, DESIGN section 5)
+    assert ring(32, 10, 4096, 4096, bias=1) == 0 and ring(32, 20, 1024, 192) == 0 and ring(32, 20, 256, 1024) == 0
+    assert ring(32, 16, 1024, 1024, D=88) == 0 and ring(32, 16, 1024, 1024, D=264) == -2 and ring(0, 1, 1, 1) == -1
+
+
 def test_binding_table_matches_header():
     assert sorted(_lib.SIGNATURES) == _declared()
 
 
 def test_version_and_error_strings_need_no_gpu():
     lib = _lib.load()
-    assert lib.pgn_version() == 110
+    assert lib.pgn_version() == 111
     assert lib.pgn_error_string(0) == b"ok"
     assert b"invalid" in lib.pgn_error_string(-1)
     assert lib.pgn_workspace_bytes(3) == 0

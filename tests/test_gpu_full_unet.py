@@ -1,0 +1,177 @@
+"""The WHOLE SDXL-shaped UNet (2.57 B parameters, all 70 transformer blocks, the 320 / 640 / 1280 skip wiring, `text_time`
+conditioning) against the fp32 CPU oracle, with FIXED bars (call site
+Pigeon/models/lavit_for_pigeon.py:752-764).
+
+tests/test_gpu_widths.py pins single modules at the real widths and tests/test_gpu_models.py a 64/128/128-channel UNet;
+neither would see a wrong skip order or `add_embedding` wiring that is self-consistent across batches.  Here the real
+architecture runs once per (dtype, latent shape) against `oracle.models_ref.unet_forward` (diffusers 0.27.2 semantics,
+PARITY UNPINNED by the reference: diffusers is not importable) at latents small enough for the host:
+32x32 (256x256 image) and the ragged 38x26 (304x208: N = 988 / 247 keys, GroupNorm rows that are no tile multiple).
+
+Protocol as in test_gpu_widths.py: weights and inputs are rounded to the 16-bit type ONCE and given to both sides; the
+oracle evaluates them in fp32.  Weights have non-zero biases and non-unit norm scales (a dropped bias must show).  The
+bars are constants: relative L2 of eps against the fp32 oracle, measured on MI355X (values beside each bar), bar =
+measured x <= 1.45; a wiring error is O(1).  Run time: ~25 s for the file (the fp32 oracle forward of the 2.57 B-parameter
+UNet at these latents takes ~1 s on the box's 16 host threads)."""
+import importlib
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import models_ref, pipeline_ref, weights
+from oracle.models_ref import Policy
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F32 = Policy(torch.float32)
+SCHED = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000,
+             steps_offset=1, clip_sample=False, set_alpha_to_one=False, timestep_spacing="leading")
+
+# every restructuring switch of the host side (INTEGRATION.md switch table), all off at once = the plain module graph
+ALL_SWITCHES = [("pigeon_amd.unet", "ACCUMULATE_ATTENTION"), ("pigeon_amd.unet", "ACCUMULATE_FF"),
+                ("pigeon_amd.attention_processor", "_FUSE_QKV"), ("pigeon_amd.layers", "FUSE_CONV_BIAS"),
+                ("pigeon_amd.layers", "SPLIT_CONCAT"), ("pigeon_amd.layers", "KEEP_DERIVED"),
+                ("pigeon_amd.layers", "HIP_UPSAMPLE")]
+
+# Measured on MI355X (round 3, two boxes; relL2 vs the fp32 oracle; whole tensor, and the worse of the two CFG rows):
+#   eps, bf16: 32x32 0.0234 (row 0.0237) default / 0.0249 (0.0272) all switches off; 38x26 0.0228 (0.0230) / 0.0223 (0.0241)
+#   eps, fp16: 32x32 0.00293 (0.00301) / 0.00327 (0.00345); 38x26 0.00286 (0.00286) / 0.00303 (0.00350)
+#   generate_image, latents after steps 0 / 1: bf16 0.02135 / 0.02136, fp16 0.00243 / 0.00243;
+#   images mean |d| 1.31 (bf16, max 15) and 0.148 (fp16, max 2) of 255; token decoder depth 12: prompt_embeds 0.0102 /
+#   0.00123, pooled 0.0055 / 0.00042.
+# Bars = worst measured x 1.25-1.4.  For scale: a 10-block Transformer2DModel alone measures 0.0155 (test_gpu_widths.py).
+UNET_BAR = {torch.bfloat16: 0.034, torch.float16: 0.0045}
+LATENT_BAR = {torch.bfloat16: 0.030, torch.float16: 0.0034}
+IMAGE_BAR = {torch.bfloat16: 2.0, torch.float16: 0.3}        # mean |d| of the uint8 images, out of 255
+
+
+def _rel(got, want):
+    got, want = got.float().cpu(), want.float().cpu()
+    return ((got - want).norm() / want.norm().clamp_min(1e-9)).item()
+
+
+def _device_synth(module, seed, dtype):
+    """weights.tensor_for's distributions, drawn on the GPU (2.57 B values in seconds instead of a minute on the host):
+    one generator per tensor seeded by (seed, crc32(name)); values rounded to `dtype` once.  Returns the fp32 host copy
+    of the ROUNDED values for the oracle."""
+    module.to_empty(device=DEV)
+    host = {}
+    with torch.no_grad():
+        for name, p in module.state_dict().items():
+            g = torch.Generator(device=DEV).manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 63))
+            leaf = name.rsplit(".", 1)[-1]
+            r = torch.randn(p.shape, generator=g, device=DEV)
+            if leaf in ("pos_embed", "query_embed"):
+                v = r * 0.02
+            elif leaf == "bias":
+                v = r * 0.02
+            elif leaf == "weight" and p.dim() == 1:
+                v = 1.0 + 0.05 * r
+            else:
+                v = r * (1.0 / max(p[0].numel(), 1)) ** 0.5
+            p.copy_(v.to(dtype))
+            host[name] = p.detach().to(dtype).float().cpu()
+    return module.to(dtype).requires_grad_(False).eval(), host
+
+
+@pytest.fixture(scope="module", params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def full(request):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pigeon_amd.unet import SDXL_CONFIG, UNet2DConditionModel
+    dt = request.param
+    with torch.device("meta"):
+        unet = UNet2DConditionModel(**SDXL_CONFIG)
+    unet, sd = _device_synth(unet, 17, dt)
+    assert sum(v.numel() for v in sd.values()) > 2.5e9
+    unet.enable_channels_last(True)
+    st = dict(dt=dt, unet=unet, sd=sd, cfg=dict(unet.config), want={})
+    yield st
+    st.clear()
+    torch.cuda.empty_cache()
+
+
+def _inputs(dt, h, w):
+    g = torch.Generator().manual_seed(1000 * h + w)
+    x = torch.randn(2, 4, h, w, generator=g).to(dt)
+    ctx = (torch.randn(2, 256, 2048, generator=g) * 0.6).to(dt)
+    ctx[0] = 0                                              # a CFG pair: row 0 is the all-zero unconditional context
+    pooled = (torch.randn(2, 1280, generator=g) * 0.5).to(dt)
+    pooled[0] = 0
+    ids = torch.tensor([[8.0 * w, 8.0 * h, 0, 0, 8.0 * w, 8.0 * h]]).repeat(2, 1).to(dt)   # (W, H, 0, 0, W, H): :791-794
+    return x, ctx, pooled, ids
+
+
+def _oracle(st, h, w):
+    if (h, w) not in st["want"]:
+        x, ctx, pooled, ids = _inputs(st["dt"], h, w)
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+        st["want"][(h, w)] = models_ref.unet_forward(F32, st["sd"], st["cfg"], x.float(), torch.tensor(641), ctx.float(),
+                                                     {"text_embeds": pooled.float(), "time_ids": ids.float()})
+    return st["want"][(h, w)]
+
+
+@pytest.mark.parametrize("switches", ["default", "all_off"])
+@pytest.mark.parametrize("hw", [(32, 32), (38, 26)], ids=["32x32", "38x26"])
+def test_whole_sdxl_unet_against_fp32_oracle(monkeypatch, full, hw, switches):
+    st, (h, w) = full, hw
+    want = _oracle(st, h, w)
+    if switches == "all_off":
+        for mod, attr in ALL_SWITCHES:
+            m = importlib.import_module(mod)
+            assert getattr(m, attr) is True
+            monkeypatch.setattr(m, attr, False)
+    x, ctx, pooled, ids = _inputs(st["dt"], h, w)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    got = st["unet"](xd, 641, encoder_hidden_states=ctx.to(DEV),
+                     added_cond_kwargs={"text_embeds": pooled.to(DEV), "time_ids": ids.to(DEV)}).sample
+    assert got.shape == (2, 4, h, w) and got.dtype == st["dt"] and torch.isfinite(got.float()).all()
+    e = _rel(got, want)
+    # the two CFG rows separately (a conditioning mix-up between rows would show in one of them)
+    e0, e1 = _rel(got[0], want[0]), _rel(got[1], want[1])
+    print(f"whole UNet {st['dt']} {h}x{w} {switches}: relL2 vs fp32 oracle {e:.5f} (rows {e0:.5f} / {e1:.5f}, "
+          f"bar {UNET_BAR[st['dt']]}); |eps| {want.abs().mean():.3f}")
+    assert max(e, e0, e1) < UNET_BAR[st["dt"]], (e, e0, e1)
+    # the conditional and unconditional rows really differ (the conditioning reaches the output)
+    assert _rel(want[0], want[1]) > 0.05
+
+
+def test_full_size_generate_image_two_steps_against_generate_image_ref(full):
+    """One full-size `generate_image` (token decoder depth 12, the whole UNet, the full VAE): 2 guided DDIM steps at
+    256x256 against `generate_image_ref` in fp32 on the host - per-step latents to a fixed bar, images by bytes."""
+    from pigeon_amd.pipeline import PigeonPixelDecoder
+    from pigeon_amd.schedulers import DDIMScheduler
+    from pigeon_amd.token_decoder import HighresVQDecoder
+    from pigeon_amd.vae import AutoencoderKL
+    st = full
+    dt = st["dt"]
+    with torch.device("meta"):
+        dec, vae = HighresVQDecoder(depth=12), AutoencoderKL()
+    dec, dec_sd = _device_synth(dec, 123, dt)
+    vae, vae_sd = _device_synth(vae, 5, dt)
+    codebook = weights.synth_codebook()
+    pipe = PigeonPixelDecoder(codebook, dec, st["unet"], vae, DDIMScheduler(**SCHED), "bf16" if dt == torch.bfloat16 else "fp16", DEV)
+    tokens = weights.synth_tokens(2, seed=9)
+    steps, H, W = 2, 256, 256
+    noise = torch.randn(2, 4, H // 8, W // 8, generator=torch.Generator().manual_seed(123))
+    got_steps = []
+    images, pe, pooled = pipe.generate_image(image_tokens=[t.to(DEV) for t in tokens], width=W, height=H,
+                                             num_inference_steps=steps, guidance_scale_for_diffusion=7.0,
+                                             latents=noise.to(DEV), output_type="uint8",
+                                             callback=lambda i, t, x: got_steps.append(x.cpu().clone()))
+    ref = pipeline_ref.generate_image_ref(F32, tokens, codebook, dec_sd, st["sd"], st["cfg"],
+                                          pipeline_ref.DDIMRef(**SCHED), noise, width=W, height=H,
+                                          num_inference_steps=steps, guidance_scale=7.0, vae_sd=vae_sd,
+                                          vae_cfg=dict(vae.config))
+    assert len(got_steps) == steps and images.shape == (2, H, W, 3)
+    print(f"full-size token decoder {dt}: prompt_embeds relL2 {_rel(pe, ref['prompt_embeds']):.5f}, pooled "
+          f"{_rel(pooled, ref['pooled']):.5f}")
+    for i, (a, b) in enumerate(zip(got_steps, ref["latents_per_step"])):
+        e = _rel(a, b)
+        print(f"full-size generate_image {dt}: latents after step {i} relL2 {e:.5f} (bar {LATENT_BAR[dt]})")
+        assert e < LATENT_BAR[dt], (i, e)
+    d = np.abs(images.cpu().numpy().astype(int) - ref["images"].astype(int))
+    print(f"full-size generate_image {dt}: images mean |d| {d.mean():.3f} / 255, max {d.max()}")
+    assert d.mean() < IMAGE_BAR[dt]

@@ -66,7 +66,7 @@ def stack():
 
 def test_native_library_is_the_one_in_tree(stack):
     from pigeon_amd import _lib
-    assert _lib.load().pgn_version() == 110
+    assert _lib.load().pgn_version() == 111
     maps = open("/proc/self/maps").read()
     assert "pigeon_amd/lib/libpigeon_hip.so" in maps
 
