@@ -4,6 +4,7 @@ Every function takes CUDA(HIP) tensors, enqueues on torch's current stream and r
 allocated through torch's caching allocator.  Nothing here computes on the CPU and nothing falls back to
 a PyTorch implementation: non-device tensors or unsupported shapes raise.
 """
+import os
 from typing import List, Optional, Sequence, Tuple, Union
 
 import torch

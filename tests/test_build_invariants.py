@@ -60,3 +60,17 @@ def test_ring_attention_softmax_arithmetic_is_not_packed(tmp_path):
     body = text[m.start():text.index(".Lfunc_end", m.start())]
     assert "v_mfma_f32_32x32x16_bf16" in body
     assert "v_pk_fma_f32" not in body and "v_pk_add_f32" not in body
+
+
+def test_python_sources_reference_no_undefined_global():
+    """A name used but never imported / assigned only fails when its line runs - on the GPU box, in a path the CPU suite
+    cannot reach (round 3: `os` in pigeon_amd/ops.py).  scripts/lint_undefined.py is a conservative AST check."""
+    import glob
+    import sys
+    files = sorted(glob.glob(os.path.join(ROOT, "pigeon_amd", "*.py")) + glob.glob(os.path.join(ROOT, "oracle", "*.py")) +
+                   glob.glob(os.path.join(ROOT, "tests", "*.py")) + [os.path.join(ROOT, "bench.py"),
+                                                                      os.path.join(ROOT, "__graft_entry__.py")])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lint_undefined.py"), *files],
+                         capture_output=True, text=True, timeout=120).stdout
+    bad = [ln for ln in out.splitlines() if "__file__" not in ln and "__name__" not in ln]
+    assert not bad, bad
