@@ -13,8 +13,17 @@ import sys
 import threading
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 os.environ["PIGEON_TUNABLEOP"] = "0"   # do not load the shipped table while producing a new one
+# Round 2 lost the record of a sweep that ended in a GPU memory fault: its log was overwritten by the next
+# run of the same name.  Every run now writes TunableOp's own trace (op signature + candidate before each trial) to a
+# file of its own that is flushed line by line, so a run that dies names the last signature / candidate it tried.
+os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "1")
+_TRACE = os.path.join(ROOT, "gpurun_out", f"tune_gemm_trace_{time.strftime('%m%d_%H%M%S')}_{os.getpid()}.stderr")
+os.makedirs(os.path.dirname(_TRACE), exist_ok=True)
+_trace_fd = os.open(_TRACE, os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+os.dup2(_trace_fd, 2)                  # C++ stderr (TunableOp, hipBLASLt, the HIP runtime's fault message) included
 import torch
 
 
@@ -73,6 +82,16 @@ def main():
         torch.cuda.synchronize()
     pass  # the table is written when the process exits
     print(f"[{time.perf_counter() - t0:6.0f}s] {len(tn.get_results())} entries", flush=True)
+    # keep the tail of the trace with the judged files (the whole trace stays in gpurun_out/)
+    try:
+        tag = f"b{args.batch}_{args.height}x{args.width}" + ("_unet_only" if args.unet_only else "")
+        with open(_TRACE, errors="replace") as fh:
+            tail = fh.readlines()[-300:]
+        with open(os.path.join(ROOT, "profiles", f"tune_gemm_{tag}_trace_tail.txt"), "w") as fh:
+            fh.write(f"# last {len(tail)} lines of {os.path.basename(_TRACE)} (PYTORCH_TUNABLEOP_VERBOSE=1), sweep completed\n")
+            fh.writelines(tail)
+    except OSError as e:
+        print(f"trace tail not copied: {e}", flush=True)
     tn.tuning_enable(False)
     with torch.no_grad():
         f = lambda: pipe.unet(x, 961, encoder_hidden_states=ctx, added_cond_kwargs={"text_embeds": add, "time_ids": ids})

@@ -9,7 +9,8 @@ inside one launch, so what has to be shown beyond the oracle bar of test_gpu_ker
     leak into the next call: back-to-back calls on ONE workspace, every element checked;
   * the full bench shape (every CU streaming, several rounds of workgroups) gives the same bits on every run.
 By default the library takes the form only for tensors of up to 32 MiB (it is slower than three passes beyond, see
-groupnorm_nhwc.hip: nh_run); PGN_GN_NHWC_ONEPASS=1 takes it wherever the shape allows, which is what these tests set.
+groupnorm_nhwc.hip: nh_run); PGN_GN_NHWC_ONEPASS=1 (mapped onto the `act` bit PGN_GN_ONEPASS_ALWAYS by
+pigeon_amd.ops) takes it wherever the shape allows, which is what these tests set.
 """
 import contextlib
 import os
@@ -46,6 +47,10 @@ def _call(lib, x, y, gamma, beta, add, G, eps, act, ws, dt=None, x2=None):
     """x: [N, HW, C1] device rows (x2: [N, HW, C2] or None); launches on the current stream, no synchronisation."""
     N, HW, C1 = x.shape
     dt = dt if dt is not None else (_lib.PGN_BF16 if x.dtype == torch.bfloat16 else _lib.PGN_F16)
+    # the library reads no environment: the form travels in `act` (PGN_GN_ONEPASS_* bits); the switches this file
+    # flips with _env are mapped onto them where the Python binding does it
+    from pigeon_amd import ops
+    act = ops._gn_nhwc_act(bool(act))
     s = torch.cuda.current_stream().cuda_stream
     ap = None if add is None else add.data_ptr()
     if x2 is None:
@@ -240,3 +245,40 @@ def test_one_pass_random_shapes_against_the_oracle():
             err = (y.cpu().float() - want.float()).abs()
             ok = err <= ulp * want.float().abs() + 4 * ulp * 2.0 ** -7 + 1e-6
             assert bool(ok.all()), (i, N, HW, C, G, with_add, act, dtype, err.max().item())
+
+
+# the one-pass form sums about ONE pivot per (sample, group) - row 0 of the group's first channel - and takes
+# var = E[d^2] - E[d]^2; the three-pass form uses per-channel pivots.  An outlier AT the pivot position makes every
+# deviation large and the subtraction cancel.  Both forms are picked at run time by tensor size (batch 4 against batch
+# 16), so both must hold the same bar on such inputs.  Pivot element at `sigmas` standard deviations from its group.
+@pytest.mark.parametrize("sigmas", [30.0, 100.0, 300.0])
+@pytest.mark.parametrize("shape", [(2, 64 * 64, 640, 32), (2, 128 * 128, 320, 32), (2, 32 * 32, 1280, 32)],
+                         ids=["c640", "c320", "c1280"])
+def test_outlier_at_the_pivot_position(shape, sigmas):
+    N, HW, C, G = shape
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(int(sigmas) + C)
+    x = torch.randn(N, HW, C, generator=g)
+    cpg = C // G
+    x[:, 0, ::cpg] = sigmas                       # row 0 of every group's first channel
+    x[1, :, cpg] += 0.25 * sigmas                 # and, in sample 1, one whole channel of group 1 with a large mean
+    x = x.to(torch.bfloat16)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(torch.bfloat16)
+    beta = (0.2 * torch.randn(C, generator=g)).to(torch.bfloat16)
+    xd = x.double().reshape(N, HW, G, cpg)                      # fp64 oracle (F.group_norm's definition)
+    mu = xd.mean(dim=(1, 3), keepdim=True)
+    var = ((xd - mu) ** 2).mean(dim=(1, 3), keepdim=True)
+    want = ((xd - mu) / torch.sqrt(var + 1e-5)).reshape(N, HW, C) * gamma.double() + beta.double()
+    want = want * torch.sigmoid(want)
+    dx, dg, db = x.to(DEV), gamma.to(DEV), beta.to(DEV)
+    ws = torch.empty(int(lib.pgn_groupnorm_nhwc_workspace_bytes(N, C, HW, G)), dtype=torch.uint8, device=DEV)
+    ulp = 2.0 ** -7
+    for name, env in (("one", {"PGN_GN_NHWC_ONEPASS": "1"}), ("three", {"PGN_GN_NHWC_ONEPASS": "0"})):
+        y = torch.empty_like(dx)
+        with _env(**env):
+            _call(lib, dx, y, dg, db, None, G, 1e-5, 1, ws)
+        torch.cuda.synchronize()
+        err = (y.cpu().double() - want).abs()
+        excess = (err - (ulp * want.abs() + 4 * ulp * 2.0 ** -7 + 1e-6)).max().item()
+        print(f"{name}-pass, pivot outlier {sigmas} sigma, C={C}: worst excess over the 1-ulp bar {excess:.3e}")
+        assert excess <= 0, (name, sigmas, excess)
