@@ -8,7 +8,8 @@
 //   kernel 1 (stats)    per (sample, row chunk): per-channel pivot-shifted sum / sum of squares, reduced over the row
 //                       lanes through LDS, written to the workspace  [N][S][C] float2
 //   kernel 2 (finalize) per (sample, group): fixed-order reduction over chunks and channels -> mean, rstd  [N][G] float2
-//                       (per-CHANNEL pivots p_c = x[n, 0, c]: sum_x (x-mu)^2 = sum_c q_c + 2 (p_c-mu) s_c + HW (p_c-mu)^2)
+//                       (per-CHANNEL pivots p_c = median of x[n, {0, HW/2, HW-1}, c]:
+//                        sum_x (x-mu)^2 = sum_c q_c + 2 (p_c-mu) s_c + HW (p_c-mu)^2)
 //   kernel 3 (apply)    same mapping as kernel 1: (x - mean) * rstd * gamma + beta, SiLU, store
 // Two reads + one write of the tensor, deterministic, no atomics.  Measured fabric traffic inside the bench is 1.5x the
 // algorithmic 1R + 1W (142 MB statistics pass + 282 MB apply pass per call at the launch-weighted shape): the apply
@@ -125,7 +126,18 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArg
         if (has_add) nh_param8(a.addnc, a.add_dt, (size_t)n * a.C + cc * 8, 0.f, tadd);
         int pitch;
         const unsigned short* xp = nh_lane_src(a, n, cc * 8, &pitch);
-        nh_load8<DT>(xp, tadd, has_add, piv);   // row 0 of the sample: one pivot per channel
+        // one pivot per channel: the MEDIAN of the channel's values in rows 0, HW / 2 and HW - 1 of the sample.  A
+        // single element (the value in row 0, until round 3) is a bad pivot exactly when it is an outlier: every
+        // deviation is then large and the finalize kernel's q + 2 (p - mu) s + HW (p - mu)^2 cancels; one outlier
+        // among three rows cannot be their median (test_outlier_at_the_pivot_position).
+        {
+            float pa[8], pb[8];
+            nh_load8<DT>(xp, tadd, has_add, piv);
+            nh_load8<DT>(xp + (size_t)(a.HW / 2) * pitch, tadd, has_add, pa);
+            nh_load8<DT>(xp + (size_t)(a.HW - 1) * pitch, tadd, has_add, pb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) piv[j] = __builtin_amdgcn_fmed3f(piv[j], pa[j], pb[j]);
+        }
         const int row1 = min(a.HW, (sc + 1) * a.rows);
         auto accum = [&](const u16x8_t& v) {
 #pragma unroll
@@ -211,9 +223,16 @@ __global__ __launch_bounds__(NH_FIN_THREADS) void pgn_gn_nhwc_finalize_kernel(Nh
         }
         const int c = g * a.cpg + t;
         int pitch;
-        p0 = Cvt<DT>::to_f32(*nh_lane_src(a, n, c, &pitch));      // per-channel pivot: row 0 of the sample
-        if (a.addnc != nullptr)
-            p0 = Cvt<DT>::to_f32(Cvt<DT>::from_f32(p0 + nh_param(a.addnc, a.add_dt, (size_t)n * a.C + c, 0.f)));
+        // per-channel pivot, as the statistics kernel took it: median of rows 0, HW / 2, HW - 1
+        const unsigned short* xc = nh_lane_src(a, n, c, &pitch);
+        float pr[3] = {Cvt<DT>::to_f32(xc[0]), Cvt<DT>::to_f32(xc[(size_t)(a.HW / 2) * pitch]),
+                       Cvt<DT>::to_f32(xc[(size_t)(a.HW - 1) * pitch])};
+        if (a.addnc != nullptr) {
+            const float ad = nh_param(a.addnc, a.add_dt, (size_t)n * a.C + c, 0.f);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pr[k] = Cvt<DT>::to_f32(Cvt<DT>::from_f32(pr[k] + ad));
+        }
+        p0 = __builtin_amdgcn_fmed3f(pr[0], pr[1], pr[2]);
     }
     const float mean = nh_fin_block_sum(v0 ? p0 + S0 / hw : 0.f, red) / (float)a.cpg;
     float var = 0.f;
@@ -284,9 +303,9 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArg
 // ---------------------------------------------------------------------------------------------------------------------
 // One-pass form: 1 read + 1 write of the tensor.  A workgroup keeps its row chunk in registers (NH_OP_ROWS 16-byte
 // loads per lane), publishes its per-group partial sums, waits until every workgroup of its sample has published,
-// reduces the S x G partials in a fixed order itself and applies from registers.  The statistics are pivot-shifted sums
-// about ONE pivot per (sample, group) - the group's first channel in row 0, which every workgroup can read for itself -
-// so that a workgroup's contribution is G words, not C.
+// reduces the S x G partials in a fixed order itself and applies from registers.  A workgroup's contribution is G
+// words, not C: per group the (mean, sum of squared deviations about that mean) of its own chunk, taken in two passes
+// over the registers; the chunks are merged with the parallel-variance update (no pivot, no E[d^2] - E[d]^2).
 //
 // Visibility between workgroups (other CUs, other XCDs) follows the guide's counter hand-off: the partials are 8-byte
 // agent-scope atomic stores (write-through), every storing wave drains vmcnt, a workgroup barrier, then one lane's
@@ -345,76 +364,124 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_onepass_kernel(NhA
         for (int i = 0; i < NH_OP_ROWS; ++i)
             if (i < nv) v[i] = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(first + i * a.R) * pitch);
     }
-    for (int g = t; g < a.G; g += blockDim.x) {                   // one pivot per (sample, group)
-        const int c0 = g * a.cpg;
-        int pp;
-        float p = Cvt<DT>::to_f32(*nh_lane_src(a, n, c0, &pp));
-        if (HAS_ADD) p = Cvt<DT>::to_f32(Cvt<DT>::from_f32(p + nh_param(a.addnc, a.add_dt, (size_t)n * a.C + c0, 0.f)));
-        shP[g] = p;
-    }
-    __syncthreads();
-    float piv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) piv[j] = active ? shP[(cc * 8 + j) / a.cpg] : 0.f;
-
-    f32x2_t s2[4], q2[4];
-    auto clear = [&]() {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) { s2[p] = f32x2_t{0.f, 0.f}; q2[p] = f32x2_t{0.f, 0.f}; }
+    // Statistics of a chunk: TWO passes over the chunk's rows (registers for the workgroup's own chunk) - per-group sum ->
+    // the chunk's own mean m, then the sum of squared deviations about m.  No pivot: a pivot element far from the group
+    // (an outlier pixel at the pivot position) made every deviation large and E[d^2] - E[d]^2 cancel (round 3 test
+    // test_outlier_at_the_pivot_position: 1.4 absolute at 300 sigma).  The S chunks of a sample are merged with the
+    // parallel-variance update (Chan et al.) in a fixed order, so nothing ever subtracts two large numbers.
+    float* shf = reinterpret_cast<float*>(shc);                  // [R][C] lane sums (one float per element)
+    auto value = [&](const u16x8_t& w, int j, const float (&ta)[8]) -> float {
+        float f = Cvt<DT>::to_f32(w[j]);
+        if constexpr (HAS_ADD) f = Cvt<DT>::to_f32(Cvt<DT>::from_f32(f + ta[j]));
+        return f;
     };
-    auto accum = [&](const u16x8_t& w) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            f32x2_t f = {Cvt<DT>::to_f32(w[2 * p]), Cvt<DT>::to_f32(w[2 * p + 1])};
-            if constexpr (HAS_ADD) {
-                f += f32x2_t{tadd[2 * p], tadd[2 * p + 1]};
-                f = f32x2_t{Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[0])), Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[1]))};
-            }
-            const f32x2_t d = f - f32x2_t{piv[2 * p], piv[2 * p + 1]};
-            s2[p] += d;
-            q2[p] += d * d;
-        }
-    };
-    // lanes' sums -> per-channel -> per-group, published as chunk `chunk` of the sample; ends behind a barrier with
-    // every storing wave drained
-    auto fold_publish = [&](int chunk) {
+    // lanes' per-channel partials -> per-channel -> per-group totals in shf[0 .. G); ends behind a barrier
+    auto fold = [&](const float (&acc)[8]) {
         if (active) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                shc[(size_t)r * a.C + cc * 8 + j] = make_float2(s2[j >> 1][j & 1], q2[j >> 1][j & 1]);
+            for (int j = 0; j < 8; ++j) shf[(size_t)r * a.C + cc * 8 + j] = acc[j];
         }
         __syncthreads();
+        float tot = 0.f;
         for (int c = t; c < a.C; c += blockDim.x) {               // column c belongs to this thread alone
-            float ss = 0.f, qq = 0.f;
-            for (int rr = 0; rr < a.R; ++rr) {
-                const float2 w = shc[(size_t)rr * a.C + c];
-                ss += w.x;
-                qq += w.y;
-            }
-            shc[c] = make_float2(ss, qq);
+            float ss = 0.f;
+            for (int rr = 0; rr < a.R; ++rr) ss += shf[(size_t)rr * a.C + c];
+            shf[c] = ss;
         }
         __syncthreads();
-        for (int g = t; g < a.G; g += blockDim.x) {
-            float ss = 0.f, qq = 0.f;
-            for (int cl = 0; cl < a.cpg; ++cl) {
-                const float2 w = shc[g * a.cpg + cl];
-                ss += w.x;
-                qq += w.y;
+        if (t < a.G) {
+            for (int cl = 0; cl < a.cpg; ++cl) tot += shf[t * a.cpg + cl];
+        }
+        __syncthreads();                                          // row 0 has been read: shf may be rewritten
+        return tot;                                               // valid in threads t < G
+    };
+    // statistics of chunk `chunk` from `rows_of(i)` (i-th row of this lane), published as (mean, M2) of the chunk
+    auto chunk_stats = [&](int chunk, int cnt_rows, auto&& row_at, int nrows, const float (&ta)[8]) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int i = 0; i < nrows; ++i) {
+            const u16x8_t w = row_at(i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += value(w, j, ta);
+        }
+        const float tot = fold(acc);
+        const float cntf = (float)cnt_rows * (float)a.cpg;
+        if (t < a.G) shP[t] = tot / cntf;                         // the chunk's own mean per group
+        __syncthreads();
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            m[j] = active ? shP[(cc * 8 + j) / a.cpg] : 0.f;
+            acc[j] = 0.f;
+        }
+        for (int i = 0; i < nrows; ++i) {
+            const u16x8_t w = row_at(i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = value(w, j, ta) - m[j];
+                acc[j] += d * d;
             }
-            const unsigned long long word = ((unsigned long long)__float_as_uint(qq) << 32) | __float_as_uint(ss);
-            __hip_atomic_store(((nh_gu64*)a.gpart) + ((size_t)n * a.S + chunk) * a.G + g, word,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const float m2 = fold(acc);
+        if (t < a.G) {
+            const unsigned long long word = ((unsigned long long)__float_as_uint(m2) << 32) | __float_as_uint(shP[t]);
+            __hip_atomic_store(((nh_gu64*)a.gpart) + ((size_t)n * a.S + chunk) * a.G + t, word, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
 
-    clear();
+    {   // own chunk, from registers (static indices: the loops are unrolled over NH_OP_ROWS with an `i < nv` guard).
+        // With add_nc the rounded sums round(x + add) REPLACE the rows in their registers first: every later pass
+        // (sum, squared deviations, apply) reads the value the reference's tensor add would have written, the add is
+        // done once instead of three times and its eight addends are dead during the passes (128-VGPR budget).
+        if constexpr (HAS_ADD) {
 #pragma unroll
-    for (int i = 0; i < NH_OP_ROWS; ++i)
-        if (i < nv) accum(v[i]);
-    NH_STAMP(1);
-    fold_publish(sc);
+            for (int i = 0; i < NH_OP_ROWS; ++i)
+                if (i < nv) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[i][j] = Cvt<DT>::from_f32(Cvt<DT>::to_f32(v[i][j]) + tadd[j]);
+                }
+        }
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NH_OP_ROWS; ++i)
+            if (i < nv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += Cvt<DT>::to_f32(v[i][j]);
+            }
+        const float tot = fold(acc);
+        if (t < a.G) shP[t] = tot / ((float)(row1 - row0) * (float)a.cpg);
+        __syncthreads();
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            m[j] = active ? shP[(cc * 8 + j) / a.cpg] : 0.f;
+            acc[j] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NH_OP_ROWS; ++i)
+            if (i < nv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = Cvt<DT>::to_f32(v[i][j]) - m[j];
+                    acc[j] += d * d;
+                }
+            }
+        NH_STAMP(1);
+        const float m2 = fold(acc);
+        if (t < a.G) {
+            const unsigned long long word = ((unsigned long long)__float_as_uint(m2) << 32) | __float_as_uint(shP[t]);
+            __hip_atomic_store(((nh_gu64*)a.gpart) + ((size_t)n * a.S + sc) * a.G + t, word, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     NH_STAMP(2);
     nh_gu32* arrived = ((nh_gu32*)a.arrived) + n;
     if (t == 0) {
@@ -430,28 +497,35 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_onepass_kernel(NhA
     __syncthreads();
     NH_STAMP(3);
     if (*shFlag == 0) {
-        // safety net: the peers have not all published within the bound; compute their chunks' words here
+        // safety net: the peers have not all published within the bound; compute their chunks' words here, with the
+        // same arithmetic in the same order (a lane walks its rows in the order the owner holds them in registers)
+        float ta[8];                                              // the addends again: not kept live across the kernel
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ta[j] = 0.f;
+        if (HAS_ADD && active) nh_param8(a.addnc, a.add_dt, (size_t)n * a.C + cc * 8, 0.f, ta);
         for (int chunk = 0; chunk < a.S; ++chunk) {
             if (chunk == sc) continue;
-            clear();
-            if (active) {
-                const int rb = min(a.HW, (chunk + 1) * a.rows);
-                for (int row = chunk * a.rows + r; row < rb; row += a.R)
-                    accum(*reinterpret_cast<const u16x8_t*>(xp + (size_t)row * pitch));
-            }
-            fold_publish(chunk);
+            const int rb = min(a.HW, (chunk + 1) * a.rows), ra = chunk * a.rows;
+            const int first = ra + r;
+            const int nrows = (active && first < rb) ? (rb - first + a.R - 1) / a.R : 0;
+            chunk_stats(chunk, rb - ra,
+                        [&](int i) { return *reinterpret_cast<const u16x8_t*>(xp + (size_t)(first + i * a.R) * pitch); },
+                        nrows, ta);
         }
     }
     if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    {   // S x G words -> G statistics, fixed order: chunk lanes stride over the chunks, then the lanes in order
+    {   // S x G words -> G statistics in a fixed order: chunk lane ls merges chunks ls, ls + L, ... one after the other,
+        // then the L lanes are merged in order.  Merge of (n_a, m_a, M2_a) with (n_b, m_b, M2_b):
+        //   d = m_b - m_a;  n = n_a + n_b;  m = m_a + d n_b / n;  M2 = M2_a + M2_b + d^2 n_a n_b / n
         const int L = blockDim.x / a.G;
         const int ls = t / a.G, g = t - ls * a.G;
+        auto chunk_cnt = [&](int c2) { return (float)(min(a.HW, (c2 + 1) * a.rows) - c2 * a.rows) * (float)a.cpg; };
         if (ls < L) {
-            float ss = 0.f, qq = 0.f;
+            float cn = 0.f, cm = 0.f, cM2 = 0.f;
             const nh_gu64* p = ((const nh_gu64*)a.gpart) + (size_t)n * a.S * a.G + g;
-            for (int c2 = ls; c2 < a.S; c2 += 8 * L) {            // eight loads in flight, summed in chunk order
+            for (int c2 = ls; c2 < a.S; c2 += 8 * L) {            // eight loads in flight, merged in chunk order
                 unsigned long long word[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
@@ -461,25 +535,34 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_onepass_kernel(NhA
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (c2 + u * L < a.S) {
-                        ss += __uint_as_float((unsigned)word[u]);
-                        qq += __uint_as_float((unsigned)(word[u] >> 32));
+                        const float nb = chunk_cnt(c2 + u * L);
+                        const float mb = __uint_as_float((unsigned)word[u]), M2b = __uint_as_float((unsigned)(word[u] >> 32));
+                        const float nn = cn + nb, d = mb - cm, f = nb / nn;
+                        cm += d * f;
+                        cM2 += M2b + d * d * cn * f;
+                        cn = nn;
                     }
                 }
             }
-            shL[ls * a.G + g] = make_float2(ss, qq);
+            shL[ls * a.G + g] = make_float2(cm, cM2);
         }
         __syncthreads();
         if (t < a.G) {
-            float ss = 0.f, qq = 0.f;
-            for (int l = 0; l < L; ++l) {
+            float cn = 0.f, cm = 0.f, cM2 = 0.f;
+            for (int l = 0; l < L && l < a.S; ++l) {
+                // elements merged by chunk lane l: chunks l, l + L, ... (all full but possibly the sample's last one)
+                const int k = (a.S - l + L - 1) / L;
+                float nb = (float)k * (float)a.rows;
+                if ((a.S - 1) % L == l) nb -= (float)(a.S * a.rows - a.HW);
+                nb *= (float)a.cpg;
                 const float2 w = shL[l * a.G + t];
-                ss += w.x;
-                qq += w.y;
+                const float nn = cn + nb, d = w.x - cm, f = nb / nn;
+                cm += d * f;
+                cM2 += w.y + d * d * cn * f;
+                cn = nn;
             }
-            const float cnt = (float)a.cpg * (float)a.HW;
-            const float md = ss / cnt;
-            const float var = fmaxf(qq / cnt - md * md, 0.f);
-            shS[t] = make_float2(shP[t] + md, 1.0f / sqrtf(var + a.eps));
+            const float var = fmaxf(cM2 / cn, 0.f);
+            shS[t] = make_float2(cm, 1.0f / sqrtf(var + a.eps));
         }
         __syncthreads();
     }
@@ -501,11 +584,7 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_onepass_kernel(NhA
             u16x8_t o;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                f32x2_t f = {Cvt<DT>::to_f32(v[i][2 * p]), Cvt<DT>::to_f32(v[i][2 * p + 1])};
-                if constexpr (HAS_ADD) {
-                    f += f32x2_t{tadd[2 * p], tadd[2 * p + 1]};
-                    f = f32x2_t{Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[0])), Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[1]))};
-                }
+                const f32x2_t f = {Cvt<DT>::to_f32(v[i][2 * p]), Cvt<DT>::to_f32(v[i][2 * p + 1])};   // add_nc: already in
                 f32x2_t w = (f - f32x2_t{mean[2 * p], mean[2 * p + 1]}) * f32x2_t{ga[2 * p], ga[2 * p + 1]} +
                             f32x2_t{be[2 * p], be[2 * p + 1]};
                 if constexpr (ACT) {
@@ -532,6 +611,345 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_onepass_kernel(NhA
     }
 #endif
 #undef NH_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pipelined one-pass form for LARGE tensors (round 3; 1 read + 1 write like the form above).
+// Why the form above loses on a saturated chip (batch 32: 0.70-0.87x of the three passes): between publishing its
+// partial statistics and applying them a workgroup WAITS for the slowest workgroup of its sample (median 21 us of a
+// 47 us life, scripts/gn_wg_timeline.py) with its rows parked in registers and nothing in flight.  Here the wait is
+// taken out of the critical path by software pipelining inside PERSISTENT workgroups (two per CU): a workgroup walks
+// items (sample, row chunk) w, w + P, w + 2 P, ... and keeps two items in registers (2 x NH_PP_ROWS 16-byte rows per
+// lane).  Per step: statistics of item k -> publish -> arrive; THEN finish item k - 1 (its sample's statistics were
+// published a whole step ago by everybody, so the wait is normally over before it starts) -> apply from registers ->
+// store; then the loads of item k + 1 go into the registers just freed.  Items of one sample are consecutive, so its
+// chunks sit on different workgroups at the same (or the neighbouring) step.
+// The S x G words of a sample are merged ONCE, by the workgroup that arrives last (fetch_add returns S - 1): it
+// publishes G (mean, rstd) words and bumps the counter to S + 1, which is what finish() waits for; every other
+// workgroup reads 8 G bytes instead of 8 S G.  Same chunk statistics, same fixed-order merge as the form above: the
+// result does not depend on who merges.  Visibility: the counter hand-off described above, twice.
+// Progress never depends on residency or dispatch order: publishing always precedes waiting within a step, every
+// wait is bounded, and a workgroup whose wait runs out computes the sample's statistics itself (all chunks from
+// global memory, same arithmetic, same order).  x and y must not overlap.
+constexpr int NH_PP_ROWS = 8;
+
+template <int DT, bool HAS_ADD, bool ACT>
+__global__ __launch_bounds__(512, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) float2 sh[];
+    float* shf = reinterpret_cast<float*>(sh);                            // [R][C] lane sums
+    float2* shL = reinterpret_cast<float2*>(shf + (size_t)a.R * a.C);     // [threads] chunk-lane partial merges
+    float2* shS = shL + blockDim.x;                                       // [G] mean, rstd of the item being finished
+    float* shP = reinterpret_cast<float*>(shS + NH_OP_MAX_G);             // [G] a chunk's own means
+    int* shFlag = reinterpret_cast<int*>(shP + NH_OP_MAX_G);              // [2]
+    const int t = threadIdx.x, P = gridDim.x, w = blockIdx.x;
+    const int r = t / a.C8, cc = t - r * a.C8;
+    const bool active = r < a.R;
+    const int nst = (n_items - w + P - 1) / P;
+    nh_gu64* gstat = (nh_gu64*)a.stats;                                   // [N][G] {mean, rstd} words
+
+    struct Item { int n, sc, first, nv, cnt; };
+    auto item = [&](int k) {
+        Item it;
+        const int idx = w + k * P;
+        it.n = idx / a.S;
+        it.sc = idx - it.n * a.S;
+        const int row0 = it.sc * a.rows, row1 = min(a.HW, row0 + a.rows);
+        it.first = row0 + r;
+        it.nv = (active && it.first < row1) ? (row1 - it.first + a.R - 1) / a.R : 0;
+        it.cnt = row1 - row0;
+        return it;
+    };
+    auto load = [&](u16x8_t (&v)[NH_PP_ROWS], const Item& it) {
+        if (!active) return;
+        int pitch;
+        const unsigned short* xp = nh_lane_src(a, it.n, cc * 8, &pitch);
+#pragma unroll
+        for (int i = 0; i < NH_PP_ROWS; ++i)
+            if (i < it.nv) v[i] = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(it.first + i * a.R) * pitch);
+    };
+    // lanes' per-channel partials -> per-channel -> per-group totals (valid in threads t < G); ends behind a barrier
+    auto fold = [&](const float (&acc)[8]) {
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) shf[(size_t)r * a.C + cc * 8 + j] = acc[j];
+        }
+        __syncthreads();
+        float tot = 0.f;
+        for (int c = t; c < a.C; c += blockDim.x) {
+            float ss = 0.f;
+            for (int rr = 0; rr < a.R; ++rr) ss += shf[(size_t)rr * a.C + c];
+            shf[c] = ss;
+        }
+        __syncthreads();
+        if (t < a.G) {
+            for (int cl = 0; cl < a.cpg; ++cl) tot += shf[t * a.cpg + cl];
+        }
+        __syncthreads();
+        return tot;
+    };
+    // (mean, M2) of one chunk from NROWS rows per lane supplied by row_at(i) (already holding round(x + add)),
+    // published as word (n, chunk)
+    auto publish_chunk = [&](int n, int chunk, int cnt_rows, int nrows, auto&& row_at) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int i = 0; i < nrows; ++i) {
+            const u16x8_t wv = row_at(i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += Cvt<DT>::to_f32(wv[j]);
+        }
+        const float tot = fold(acc);
+        if (t < a.G) shP[t] = tot / ((float)cnt_rows * (float)a.cpg);
+        __syncthreads();
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            m[j] = active ? shP[(cc * 8 + j) / a.cpg] : 0.f;
+            acc[j] = 0.f;
+        }
+        for (int i = 0; i < nrows; ++i) {
+            const u16x8_t wv = row_at(i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = Cvt<DT>::to_f32(wv[j]) - m[j];
+                acc[j] += d * d;
+            }
+        }
+        const float m2 = fold(acc);
+        if (t < a.G) {
+            const unsigned long long word = ((unsigned long long)__float_as_uint(m2) << 32) | __float_as_uint(shP[t]);
+            __hip_atomic_store(((nh_gu64*)a.gpart) + ((size_t)n * a.S + chunk) * a.G + t, word, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    // S x G words of sample n -> shS[g] = (mean, rstd); fixed order (see pgn_gn_nhwc_onepass_kernel).  The caller has
+    // made the words visible (acquire + drain + barrier).
+    auto merge = [&](int n) {
+        const int L = blockDim.x / a.G;
+        const int ls = t / a.G, g = t - ls * a.G;
+        auto chunk_cnt = [&](int c2) { return (float)(min(a.HW, (c2 + 1) * a.rows) - c2 * a.rows) * (float)a.cpg; };
+        if (ls < L) {
+            float cn = 0.f, cm = 0.f, cM2 = 0.f;
+            const nh_gu64* p = ((const nh_gu64*)a.gpart) + (size_t)n * a.S * a.G + g;
+            for (int c2 = ls; c2 < a.S; c2 += 8 * L) {
+                unsigned long long word[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    word[u] = c2 + u * L < a.S ? __hip_atomic_load(p + (size_t)(c2 + u * L) * a.G, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT)
+                                               : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (c2 + u * L < a.S) {
+                        const float nb = chunk_cnt(c2 + u * L);
+                        const float mb = __uint_as_float((unsigned)word[u]), M2b = __uint_as_float((unsigned)(word[u] >> 32));
+                        const float nn = cn + nb, d = mb - cm, f = nb / nn;
+                        cm += d * f;
+                        cM2 += M2b + d * d * cn * f;
+                        cn = nn;
+                    }
+                }
+            }
+            shL[ls * a.G + g] = make_float2(cm, cM2);
+        }
+        __syncthreads();
+        if (t < a.G) {
+            float cn = 0.f, cm = 0.f, cM2 = 0.f;
+            for (int l = 0; l < L && l < a.S; ++l) {
+                const int k = (a.S - l + L - 1) / L;
+                float nb = (float)k * (float)a.rows;
+                if ((a.S - 1) % L == l) nb -= (float)(a.S * a.rows - a.HW);
+                nb *= (float)a.cpg;
+                const float2 wv = shL[l * a.G + t];
+                const float nn = cn + nb, d = wv.x - cm, f = nb / nn;
+                cm += d * f;
+                cM2 += wv.y + d * d * cn * f;
+                cn = nn;
+            }
+            const float var = fmaxf(cM2 / cn, 0.f);
+            shS[t] = make_float2(cm, 1.0f / sqrtf(var + a.eps));
+        }
+        __syncthreads();
+    };
+    // statistics of an item held in registers: pre-add, publish, arrive; the last arriver merges for the sample
+    auto stats = [&](u16x8_t (&v)[NH_PP_ROWS], const Item& it) {
+        if constexpr (HAS_ADD) {
+            if (active) {
+                float ta[8];
+                nh_param8(a.addnc, a.add_dt, (size_t)it.n * a.C + cc * 8, 0.f, ta);
+#pragma unroll
+                for (int i = 0; i < NH_PP_ROWS; ++i)
+                    if (i < it.nv) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[i][j] = Cvt<DT>::from_f32(Cvt<DT>::to_f32(v[i][j]) + ta[j]);
+                    }
+            }
+        }
+        {   // as publish_chunk, over the registers (static indices)
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NH_PP_ROWS; ++i)
+                if (i < it.nv) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += Cvt<DT>::to_f32(v[i][j]);
+                }
+            const float tot = fold(acc);
+            if (t < a.G) shP[t] = tot / ((float)it.cnt * (float)a.cpg);
+            __syncthreads();
+            float m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                m[j] = active ? shP[(cc * 8 + j) / a.cpg] : 0.f;
+                acc[j] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < NH_PP_ROWS; ++i)
+                if (i < it.nv) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float d = Cvt<DT>::to_f32(v[i][j]) - m[j];
+                        acc[j] += d * d;
+                    }
+                }
+            const float m2 = fold(acc);
+            if (t < a.G) {
+                const unsigned long long word = ((unsigned long long)__float_as_uint(m2) << 32) | __float_as_uint(shP[t]);
+                __hip_atomic_store(((nh_gu64*)a.gpart) + ((size_t)it.n * a.S + it.sc) * a.G + t, word, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        nh_gu32* arrived = ((nh_gu32*)a.arrived) + it.n;
+        if (t == 0) shFlag[0] = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.S - 1);
+        __syncthreads();
+        if (shFlag[0]) {                                          // every chunk of the sample has been published
+            if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            merge(it.n);
+            if (t < a.G) {
+                const float2 st = shS[t];
+                const unsigned long long word = ((unsigned long long)__float_as_uint(st.y) << 32) | __float_as_uint(st.x);
+                __hip_atomic_store(gstat + (size_t)it.n * a.G + t, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // S + 1
+        }
+    };
+    // wait for the sample's statistics, apply them to the item's rows, store
+    auto finish = [&](u16x8_t (&v)[NH_PP_ROWS], const Item& it) {
+        nh_gu32* arrived = ((nh_gu32*)a.arrived) + it.n;
+        if (t == 0) {
+            int ok = 1;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(a.S + 1)) {
+                if (__builtin_amdgcn_s_memrealtime() - t0 >= (unsigned long long)a.timeout) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            shFlag[1] = ok;
+        }
+        __syncthreads();
+        if (shFlag[1]) {
+            if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t < a.G) {
+                const unsigned long long word = __hip_atomic_load(gstat + (size_t)it.n * a.G + t, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT);
+                shS[t] = make_float2(__uint_as_float((unsigned)word), __uint_as_float((unsigned)(word >> 32)));
+            }
+            __syncthreads();
+        } else {
+            // safety net: the sample's statistics did not appear within the bound - compute them here from global memory
+            // (every chunk but the own one, whose word this workgroup has published; identical words are rewritten)
+            int pitch = 0;
+            const unsigned short* xp = active ? nh_lane_src(a, it.n, cc * 8, &pitch) : nullptr;
+            float ta[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ta[j] = 0.f;
+            if (HAS_ADD && active) nh_param8(a.addnc, a.add_dt, (size_t)it.n * a.C + cc * 8, 0.f, ta);
+            for (int chunk = 0; chunk < a.S; ++chunk) {
+                if (chunk == it.sc) continue;
+                const int ra = chunk * a.rows, rb = min(a.HW, ra + a.rows);
+                const int first = ra + r;
+                const int nrows = (active && first < rb) ? (rb - first + a.R - 1) / a.R : 0;
+                publish_chunk(it.n, chunk, rb - ra, nrows, [&](int i) {
+                    u16x8_t wv = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(first + i * a.R) * pitch);
+                    if constexpr (HAS_ADD) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) wv[j] = Cvt<DT>::from_f32(Cvt<DT>::to_f32(wv[j]) + ta[j]);
+                    }
+                    return wv;
+                });
+            }
+            if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            merge(it.n);
+        }
+        if (active) {
+            float mean[8], ga[8], be[8];
+            nh_param8(a.gamma, a.adt, (size_t)cc * 8, 1.f, ga);
+            nh_param8(a.beta, a.adt, (size_t)cc * 8, 0.f, be);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float2 st = shS[(cc * 8 + j) / a.cpg];
+                mean[j] = st.x;
+                ga[j] *= st.y;
+            }
+            unsigned short* yp = reinterpret_cast<unsigned short*>(a.y) + (size_t)it.n * a.HW * a.C +
+                                 (size_t)it.first * a.C + cc * 8;
+#pragma unroll
+            for (int i = 0; i < NH_PP_ROWS; ++i) {
+                if (i < it.nv) {
+                    u16x8_t o;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const f32x2_t f = {Cvt<DT>::to_f32(v[i][2 * p]), Cvt<DT>::to_f32(v[i][2 * p + 1])};
+                        f32x2_t wv = (f - f32x2_t{mean[2 * p], mean[2 * p + 1]}) * f32x2_t{ga[2 * p], ga[2 * p + 1]} +
+                                     f32x2_t{be[2 * p], be[2 * p + 1]};
+                        if constexpr (ACT) {
+                            const f32x2_t x2 = wv * f32x2_t{-1.4426950408889634f, -1.4426950408889634f};
+                            f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])} + f32x2_t{1.0f, 1.0f};
+                            wv = wv * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                        }
+                        o[2 * p] = Cvt<DT>::from_f32(wv[0]);
+                        o[2 * p + 1] = Cvt<DT>::from_f32(wv[1]);
+                    }
+                    *reinterpret_cast<u16x8_t*>(yp + (size_t)i * a.R * a.C) = o;
+                }
+            }
+        }
+        __syncthreads();                                          // shS is rewritten by the next finish / merge
+    };
+
+    u16x8_t va[NH_PP_ROWS], vb[NH_PP_ROWS];
+    Item ia = item(0), ib = ia;
+    load(va, ia);
+    for (int k = 0; k < nst; k += 2) {
+        stats(va, ia);
+        if (k > 0) finish(vb, ib);
+        if (k + 1 >= nst) {
+            finish(va, ia);
+            break;
+        }
+        ib = item(k + 1);
+        load(vb, ib);
+        stats(vb, ib);
+        finish(va, ia);
+        if (k + 2 >= nst) {
+            finish(vb, ib);
+            break;
+        }
+        ia = item(k + 2);
+        load(va, ia);
+    }
 }
 
 // workgroups aimed at per launch, minimum rows per lane: swept on MI355X (scripts/gn_exp.py): fewer, longer workgroups
