@@ -618,9 +618,9 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_onepass_kernel(NhA
 // Why the form above loses on a saturated chip (batch 32: 0.70-0.87x of the three passes): between publishing its
 // partial statistics and applying them a workgroup WAITS for the slowest workgroup of its sample (median 21 us of a
 // 47 us life, scripts/gn_wg_timeline.py) with its rows parked in registers and nothing in flight.  Here the wait is
-// taken out of the critical path by software pipelining inside PERSISTENT workgroups (two per CU): a workgroup walks
-// items (sample, row chunk) w, w + P, w + 2 P, ... and keeps two items in registers (2 x NH_PP_ROWS 16-byte rows per
-// lane).  Per step: statistics of item k -> publish -> arrive; THEN finish item k - 1 (its sample's statistics were
+// taken out of the critical path by software pipelining inside PERSISTENT workgroups (two of <= 256 threads per CU): a
+// workgroup walks items (sample, row chunk) w, w + P, w + 2 P, ... and keeps two items in registers (2 x NH_PP_ROWS
+// 16-byte rows per lane = 128 VGPRs).  Per step: statistics of item k -> publish -> arrive; THEN finish item k - 1 (its sample's statistics were
 // published a whole step ago by everybody, so the wait is normally over before it starts) -> apply from registers ->
 // store; then the loads of item k + 1 go into the registers just freed.  Items of one sample are consecutive, so its
 // chunks sit on different workgroups at the same (or the neighbouring) step.
@@ -631,41 +631,53 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_onepass_kernel(NhA
 // Progress never depends on residency or dispatch order: publishing always precedes waiting within a step, every
 // wait is bounded, and a workgroup whose wait runs out computes the sample's statistics itself (all chunks from
 // global memory, same arithmetic, same order).  x and y must not overlap.
-constexpr int NH_PP_ROWS = 8;
+constexpr int NH_PP_ROWS = 16;
 
 template <int DT, bool HAS_ADD, bool ACT>
-__global__ __launch_bounds__(512, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int n_items) {
+__global__ __launch_bounds__(256, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int n_items) {
     extern __shared__ __attribute__((aligned(16))) float2 sh[];
     float* shf = reinterpret_cast<float*>(sh);                            // [R][C] lane sums
     float2* shL = reinterpret_cast<float2*>(shf + (size_t)a.R * a.C);     // [threads] chunk-lane partial merges
     float2* shS = shL + blockDim.x;                                       // [G] mean, rstd of the item being finished
     float* shP = reinterpret_cast<float*>(shS + NH_OP_MAX_G);             // [G] a chunk's own means
     int* shFlag = reinterpret_cast<int*>(shP + NH_OP_MAX_G);              // [2]
-    const int t = threadIdx.x, P = gridDim.x, w = blockIdx.x;
-    const int r = t / a.C8, cc = t - r * a.C8;
-    const bool active = r < a.R;
+    const int P = gridDim.x, w = blockIdx.x;
+    // The lane's coordinates are RE-DERIVED from an opaque copy of the thread id at the top of every step: as loop
+    // invariants of the persistent loop, everything computed from them (eight group indices, LDS and parameter
+    // addresses, source pointers) is hoisted to kernel entry and kept live across the loop.  A few integer divisions
+    // per ~60 KB item are cheaper.
+    int t = threadIdx.x;
+    int r = t / a.C8, cc = t - r * a.C8;
+    bool active = r < a.R;
     const int nst = (n_items - w + P - 1) / P;
     nh_gu64* gstat = (nh_gu64*)a.stats;                                   // [N][G] {mean, rstd} words
 
-    struct Item { int n, sc, first, nv, cnt; };
+    // An item lives in registers only when its chunk is FULL (every active lane holds exactly NH_PP_ROWS rows: no
+    // per-row conditions anywhere).  The one short chunk a sample may end with (HW % rows != 0: < 1 % of the rows)
+    // takes the global-memory path the safety net uses: its statistics read it twice, its apply a third time.
+    struct Item { int n, sc, row0, row1; bool full; };
     auto item = [&](int k) {
         Item it;
         const int idx = w + k * P;
         it.n = idx / a.S;
         it.sc = idx - it.n * a.S;
-        const int row0 = it.sc * a.rows, row1 = min(a.HW, row0 + a.rows);
-        it.first = row0 + r;
-        it.nv = (active && it.first < row1) ? (row1 - it.first + a.R - 1) / a.R : 0;
-        it.cnt = row1 - row0;
+        it.row0 = it.sc * a.rows;
+        it.row1 = min(a.HW, it.row0 + a.rows);
+        it.full = it.row1 - it.row0 == a.rows;
         return it;
     };
+    // one running 32-bit byte offset per access stream (a sample is < 4 GiB: checked on the host)
     auto load = [&](u16x8_t (&v)[NH_PP_ROWS], const Item& it) {
-        if (!active) return;
+        if (!active || !it.full) return;
         int pitch;
-        const unsigned short* xp = nh_lane_src(a, it.n, cc * 8, &pitch);
+        const char* xp = reinterpret_cast<const char*>(nh_lane_src(a, it.n, cc * 8, &pitch));
+        unsigned off = (unsigned)(it.row0 + r) * (unsigned)pitch * 2u;
+        const unsigned step = (unsigned)a.R * (unsigned)pitch * 2u;
 #pragma unroll
-        for (int i = 0; i < NH_PP_ROWS; ++i)
-            if (i < it.nv) v[i] = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(it.first + i * a.R) * pitch);
+        for (int i = 0; i < NH_PP_ROWS; ++i) {
+            v[i] = *reinterpret_cast<const u16x8_t*>(xp + off);
+            off += step;
+        }
     };
     // lanes' per-channel partials -> per-channel -> per-group totals (valid in threads t < G); ends behind a barrier
     auto fold = [&](const float (&acc)[8]) {
@@ -687,35 +699,8 @@ __global__ __launch_bounds__(512, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int 
         __syncthreads();
         return tot;
     };
-    // (mean, M2) of one chunk from NROWS rows per lane supplied by row_at(i) (already holding round(x + add)),
-    // published as word (n, chunk)
-    auto publish_chunk = [&](int n, int chunk, int cnt_rows, int nrows, auto&& row_at) {
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        for (int i = 0; i < nrows; ++i) {
-            const u16x8_t wv = row_at(i);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += Cvt<DT>::to_f32(wv[j]);
-        }
-        const float tot = fold(acc);
-        if (t < a.G) shP[t] = tot / ((float)cnt_rows * (float)a.cpg);
-        __syncthreads();
-        float m[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            m[j] = active ? shP[(cc * 8 + j) / a.cpg] : 0.f;
-            acc[j] = 0.f;
-        }
-        for (int i = 0; i < nrows; ++i) {
-            const u16x8_t wv = row_at(i);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = Cvt<DT>::to_f32(wv[j]) - m[j];
-                acc[j] += d * d;
-            }
-        }
-        const float m2 = fold(acc);
+    // store the chunk's word (its own mean per group is in shP, its M2 in m2 of threads t < G); drained + barrier
+    auto publish_word = [&](int n, int chunk, float m2) {
         if (t < a.G) {
             const unsigned long long word = ((unsigned long long)__float_as_uint(m2) << 32) | __float_as_uint(shP[t]);
             __hip_atomic_store(((nh_gu64*)a.gpart) + ((size_t)n * a.S + chunk) * a.G + t, word, __ATOMIC_RELAXED,
@@ -723,6 +708,59 @@ __global__ __launch_bounds__(512, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    };
+    // one row of a lane from global memory, holding round(x + add) like the rows kept in registers
+    auto row_from_memory = [&](const char* xp, unsigned off, const float (&ta)[8]) {
+        u16x8_t wv = *reinterpret_cast<const u16x8_t*>(xp + off);
+        if constexpr (HAS_ADD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = Cvt<DT>::from_f32(Cvt<DT>::to_f32(wv[j]) + ta[j]);
+        }
+        return wv;
+    };
+    // (mean, M2) of chunk `chunk` of sample n straight from global memory (two reads), published; same arithmetic in
+    // the same order as the register path: a lane walks its rows first, first + R, ...
+    auto publish_chunk_from_memory = [&](int n, int chunk) {
+        const int ra = chunk * a.rows, rb = min(a.HW, ra + a.rows);
+        int pitch = 0;
+        const char* xp = active ? reinterpret_cast<const char*>(nh_lane_src(a, n, cc * 8, &pitch)) : nullptr;
+        float ta[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ta[j] = 0.f;
+        if (HAS_ADD && active) nh_param8(a.addnc, a.add_dt, (size_t)n * a.C + cc * 8, 0.f, ta);
+        const unsigned step = (unsigned)a.R * (unsigned)pitch * 2u;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        if (active) {
+            unsigned off = (unsigned)(ra + r) * (unsigned)pitch * 2u;
+            for (int row = ra + r; row < rb; row += a.R, off += step) {
+                const u16x8_t wv = row_from_memory(xp, off, ta);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += Cvt<DT>::to_f32(wv[j]);
+            }
+        }
+        const float tot = fold(acc);
+        if (t < a.G) shP[t] = tot / ((float)(rb - ra) * (float)a.cpg);
+        __syncthreads();
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            m[j] = active ? shP[(cc * 8 + j) / a.cpg] : 0.f;
+            acc[j] = 0.f;
+        }
+        if (active) {
+            unsigned off = (unsigned)(ra + r) * (unsigned)pitch * 2u;
+            for (int row = ra + r; row < rb; row += a.R, off += step) {
+                const u16x8_t wv = row_from_memory(xp, off, ta);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = Cvt<DT>::to_f32(wv[j]) - m[j];
+                    acc[j] += d * d;
+                }
+            }
+        }
+        publish_word(n, chunk, fold(acc));
     };
     // S x G words of sample n -> shS[g] = (mean, rstd); fixed order (see pgn_gn_nhwc_onepass_kernel).  The caller has
     // made the words visible (acquire + drain + barrier).
@@ -733,15 +771,15 @@ __global__ __launch_bounds__(512, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int 
         if (ls < L) {
             float cn = 0.f, cm = 0.f, cM2 = 0.f;
             const nh_gu64* p = ((const nh_gu64*)a.gpart) + (size_t)n * a.S * a.G + g;
-            for (int c2 = ls; c2 < a.S; c2 += 8 * L) {
-                unsigned long long word[8];
+            for (int c2 = ls; c2 < a.S; c2 += 4 * L) {
+                unsigned long long word[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < 4; ++u)
                     word[u] = c2 + u * L < a.S ? __hip_atomic_load(p + (size_t)(c2 + u * L) * a.G, __ATOMIC_RELAXED,
                                                                   __HIP_MEMORY_SCOPE_AGENT)
                                                : 0ull;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 4; ++u) {
                     if (c2 + u * L < a.S) {
                         const float nb = chunk_cnt(c2 + u * L);
                         const float mb = __uint_as_float((unsigned)word[u]), M2b = __uint_as_float((unsigned)(word[u] >> 32));
@@ -773,32 +811,28 @@ __global__ __launch_bounds__(512, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int 
         }
         __syncthreads();
     };
-    // statistics of an item held in registers: pre-add, publish, arrive; the last arriver merges for the sample
+    // statistics of an item: pre-add, publish, arrive; the last arriver merges for the sample
     auto stats = [&](u16x8_t (&v)[NH_PP_ROWS], const Item& it) {
-        if constexpr (HAS_ADD) {
-            if (active) {
-                float ta[8];
-                nh_param8(a.addnc, a.add_dt, (size_t)it.n * a.C + cc * 8, 0.f, ta);
+        if (it.full) {
+            if constexpr (HAS_ADD) {
+                if (active) {
+                    float ta[8];
+                    nh_param8(a.addnc, a.add_dt, (size_t)it.n * a.C + cc * 8, 0.f, ta);
 #pragma unroll
-                for (int i = 0; i < NH_PP_ROWS; ++i)
-                    if (i < it.nv) {
+                    for (int i = 0; i < NH_PP_ROWS; ++i)
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[i][j] = Cvt<DT>::from_f32(Cvt<DT>::to_f32(v[i][j]) + ta[j]);
-                    }
+                }
             }
-        }
-        {   // as publish_chunk, over the registers (static indices)
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
             for (int i = 0; i < NH_PP_ROWS; ++i)
-                if (i < it.nv) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += Cvt<DT>::to_f32(v[i][j]);
-                }
+                for (int j = 0; j < 8; ++j) acc[j] += Cvt<DT>::to_f32(v[i][j]);
             const float tot = fold(acc);
-            if (t < a.G) shP[t] = tot / ((float)it.cnt * (float)a.cpg);
+            if (t < a.G) shP[t] = tot / ((float)a.rows * (float)a.cpg);
             __syncthreads();
             float m[8];
 #pragma unroll
@@ -806,23 +840,20 @@ __global__ __launch_bounds__(512, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int 
                 m[j] = active ? shP[(cc * 8 + j) / a.cpg] : 0.f;
                 acc[j] = 0.f;
             }
+            // the rows stay PACKED between the passes: without this the compiler keeps the 128 widened fp32 values of
+            // the first pass for the second one and for the apply (another 128 VGPRs, i.e. spills)
+#pragma unroll
+            for (int i = 0; i < NH_PP_ROWS; ++i) asm volatile("" : "+v"(v[i]));
 #pragma unroll
             for (int i = 0; i < NH_PP_ROWS; ++i)
-                if (i < it.nv) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float d = Cvt<DT>::to_f32(v[i][j]) - m[j];
-                        acc[j] += d * d;
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const float d = Cvt<DT>::to_f32(v[i][j]) - m[j];
+                    acc[j] += d * d;
                 }
-            const float m2 = fold(acc);
-            if (t < a.G) {
-                const unsigned long long word = ((unsigned long long)__float_as_uint(m2) << 32) | __float_as_uint(shP[t]);
-                __hip_atomic_store(((nh_gu64*)a.gpart) + ((size_t)it.n * a.S + it.sc) * a.G + t, word, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            publish_word(it.n, it.sc, fold(acc));
+        } else {
+            publish_chunk_from_memory(it.n, it.sc);
         }
         nh_gu32* arrived = ((nh_gu32*)a.arrived) + it.n;
         if (t == 0) shFlag[0] = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.S - 1);
@@ -841,6 +872,23 @@ __global__ __launch_bounds__(512, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int 
             __syncthreads();
             if (t == 0) __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // S + 1
         }
+    };
+    auto apply_row = [&](const u16x8_t& wv_in, const float (&mean)[8], const float (&ga)[8], const float (&be)[8]) {
+        u16x8_t o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const f32x2_t f = {Cvt<DT>::to_f32(wv_in[2 * p]), Cvt<DT>::to_f32(wv_in[2 * p + 1])};
+            f32x2_t wv = (f - f32x2_t{mean[2 * p], mean[2 * p + 1]}) * f32x2_t{ga[2 * p], ga[2 * p + 1]} +
+                         f32x2_t{be[2 * p], be[2 * p + 1]};
+            if constexpr (ACT) {
+                const f32x2_t x2 = wv * f32x2_t{-1.4426950408889634f, -1.4426950408889634f};
+                f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])} + f32x2_t{1.0f, 1.0f};
+                wv = wv * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            }
+            o[2 * p] = Cvt<DT>::from_f32(wv[0]);
+            o[2 * p + 1] = Cvt<DT>::from_f32(wv[1]);
+        }
+        return o;
     };
     // wait for the sample's statistics, apply them to the item's rows, store
     auto finish = [&](u16x8_t (&v)[NH_PP_ROWS], const Item& it) {
@@ -868,25 +916,9 @@ __global__ __launch_bounds__(512, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int 
         } else {
             // safety net: the sample's statistics did not appear within the bound - compute them here from global memory
             // (every chunk but the own one, whose word this workgroup has published; identical words are rewritten)
-            int pitch = 0;
-            const unsigned short* xp = active ? nh_lane_src(a, it.n, cc * 8, &pitch) : nullptr;
-            float ta[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ta[j] = 0.f;
-            if (HAS_ADD && active) nh_param8(a.addnc, a.add_dt, (size_t)it.n * a.C + cc * 8, 0.f, ta);
             for (int chunk = 0; chunk < a.S; ++chunk) {
                 if (chunk == it.sc) continue;
-                const int ra = chunk * a.rows, rb = min(a.HW, ra + a.rows);
-                const int first = ra + r;
-                const int nrows = (active && first < rb) ? (rb - first + a.R - 1) / a.R : 0;
-                publish_chunk(it.n, chunk, rb - ra, nrows, [&](int i) {
-                    u16x8_t wv = *reinterpret_cast<const u16x8_t*>(xp + (size_t)(first + i * a.R) * pitch);
-                    if constexpr (HAS_ADD) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) wv[j] = Cvt<DT>::from_f32(Cvt<DT>::to_f32(wv[j]) + ta[j]);
-                    }
-                    return wv;
-                });
+                publish_chunk_from_memory(it.n, chunk);
             }
             if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -894,6 +926,7 @@ __global__ __launch_bounds__(512, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int 
             merge(it.n);
         }
         if (active) {
+            // y = (x - mean) * (gamma * rstd) + beta, as the other forms compute it
             float mean[8], ga[8], be[8];
             nh_param8(a.gamma, a.adt, (size_t)cc * 8, 1.f, ga);
             nh_param8(a.beta, a.adt, (size_t)cc * 8, 0.f, be);
@@ -903,54 +936,62 @@ __global__ __launch_bounds__(512, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int 
                 mean[j] = st.x;
                 ga[j] *= st.y;
             }
-            unsigned short* yp = reinterpret_cast<unsigned short*>(a.y) + (size_t)it.n * a.HW * a.C +
-                                 (size_t)it.first * a.C + cc * 8;
+            char* yp = reinterpret_cast<char*>(a.y) + ((size_t)it.n * a.HW * a.C + cc * 8) * 2;
+            unsigned off = (unsigned)(it.row0 + r) * (unsigned)a.C * 2u;
+            const unsigned step = (unsigned)a.R * (unsigned)a.C * 2u;
+            if (it.full) {
 #pragma unroll
-            for (int i = 0; i < NH_PP_ROWS; ++i) {
-                if (i < it.nv) {
-                    u16x8_t o;
+                for (int i = 0; i < NH_PP_ROWS; ++i) asm volatile("" : "+v"(v[i]));
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const f32x2_t f = {Cvt<DT>::to_f32(v[i][2 * p]), Cvt<DT>::to_f32(v[i][2 * p + 1])};
-                        f32x2_t wv = (f - f32x2_t{mean[2 * p], mean[2 * p + 1]}) * f32x2_t{ga[2 * p], ga[2 * p + 1]} +
-                                     f32x2_t{be[2 * p], be[2 * p + 1]};
-                        if constexpr (ACT) {
-                            const f32x2_t x2 = wv * f32x2_t{-1.4426950408889634f, -1.4426950408889634f};
-                            f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])} + f32x2_t{1.0f, 1.0f};
-                            wv = wv * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-                        }
-                        o[2 * p] = Cvt<DT>::from_f32(wv[0]);
-                        o[2 * p + 1] = Cvt<DT>::from_f32(wv[1]);
-                    }
-                    *reinterpret_cast<u16x8_t*>(yp + (size_t)i * a.R * a.C) = o;
+                for (int i = 0; i < NH_PP_ROWS; ++i) {
+                    *reinterpret_cast<u16x8_t*>(yp + off) = apply_row(v[i], mean, ga, be);
+                    off += step;
                 }
+            } else {                                              // short last chunk: rows from global memory again
+                int pitch;
+                const char* xp = reinterpret_cast<const char*>(nh_lane_src(a, it.n, cc * 8, &pitch));
+                float ta[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ta[j] = 0.f;
+                if (HAS_ADD) nh_param8(a.addnc, a.add_dt, (size_t)it.n * a.C + cc * 8, 0.f, ta);
+                unsigned xoff = (unsigned)(it.row0 + r) * (unsigned)pitch * 2u;
+                const unsigned xstep = (unsigned)a.R * (unsigned)pitch * 2u;
+                for (int row = it.row0 + r; row < it.row1; row += a.R, off += step, xoff += xstep)
+                    *reinterpret_cast<u16x8_t*>(yp + off) = apply_row(row_from_memory(xp, xoff, ta), mean, ga, be);
             }
         }
         __syncthreads();                                          // shS is rewritten by the next finish / merge
     };
 
-    u16x8_t va[NH_PP_ROWS], vb[NH_PP_ROWS];
-    Item ia = item(0), ib = ia;
-    load(va, ia);
-    for (int k = 0; k < nst; k += 2) {
-        stats(va, ia);
-        if (k > 0) finish(vb, ib);
-        if (k + 1 >= nst) {
-            finish(va, ia);
-            break;
+    // ONE copy of each phase in the code: the item whose statistics were just published moves to the `prev` registers
+    // (64 v_mov per item of ~60 KB) instead of the loop being unrolled over two register sets.
+    u16x8_t cur[NH_PP_ROWS], prev[NH_PP_ROWS];
+    Item ic = item(0), ip = ic;
+    load(cur, ic);
+    for (int k = 0; k <= nst; ++k) {
+        t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        r = t / a.C8;
+        cc = t - r * a.C8;
+        active = r < a.R;
+        if (k < nst) stats(cur, ic);
+        if (k > 0) finish(prev, ip);
+        if (k < nst) {
+#pragma unroll
+            for (int i = 0; i < NH_PP_ROWS; ++i) {
+                asm volatile("" : "+v"(cur[i]));
+                prev[i] = cur[i];
+            }
+            ip = ic;
+            if (k + 1 < nst) {
+                ic = item(k + 1);
+                load(cur, ic);
+            }
         }
-        ib = item(k + 1);
-        load(vb, ib);
-        stats(vb, ib);
-        finish(va, ia);
-        if (k + 2 >= nst) {
-            finish(vb, ib);
-            break;
-        }
-        ia = item(k + 2);
-        load(va, ia);
     }
 }
+
+static size_t nh_onepass_counter_bytes_fwd(int N) { return (((size_t)N * sizeof(unsigned int)) + 255) & ~(size_t)255; }
 
 // workgroups aimed at per launch, minimum rows per lane: swept on MI355X (scripts/gn_exp.py): fewer, longer workgroups
 #ifdef PGN_TUNING_HOOKS
@@ -1000,6 +1041,32 @@ static bool nh_geometry_onepass(int N, int C, int HW, int G, NhArgs* a, int* thr
     return (long long)N * a->S <= 0x7fffffffLL;
 }
 
+// pipelined form: workgroups of at most 256 threads (two per CU at 256 VGPRs: two items of NH_PP_ROWS rows per lane in
+// registers and room for the phases' working set - at 512 threads / 128 VGPRs the persistent loop spilled a whole item)
+static bool nh_geometry_pipe(int N, int C, int HW, int G, NhArgs* a, int* threads) {
+    if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return false;
+    if ((C & 7) != 0 || C / 8 > 256 || G > NH_OP_MAX_G) return false;
+    if ((long long)HW * C * 2 >= (1LL << 32)) return false;          // 32-bit byte offsets inside a sample
+    a->C = C; a->HW = HW; a->G = G; a->cpg = C / G; a->C8 = C / 8;
+    int R = 256 / a->C8;
+    if (R > HW) R = HW;
+    if (R > 64) R = 64;
+    a->R = R;
+    a->rows = NH_PP_ROWS * R;
+    a->S = (HW + a->rows - 1) / a->rows;
+    *threads = ((R * a->C8 + 63) / 64) * 64;
+    if (*threads < 64) *threads = 64;
+    if (*threads < G) return false;
+    return (long long)N * a->S <= 0x7fffffffLL;
+}
+static size_t nh_pipe_lds(const NhArgs& a, int threads) {
+    return (size_t)a.R * a.C * sizeof(float) + ((size_t)threads + NH_OP_MAX_G) * sizeof(float2) + NH_OP_MAX_G * sizeof(float) + 16;
+}
+// workspace of the pipelined form: [N] arrival counters (zeroed per call), [N][G] statistics words, [N][S][G] chunk words
+static size_t nh_pipe_workspace(int N, int G, int S) {
+    return nh_onepass_counter_bytes_fwd(N) + (size_t)N * G * 8 + (size_t)N * S * G * 8;
+}
+
 static size_t nh_onepass_lds(const NhArgs& a, int threads) {
     return ((size_t)a.R * a.C + (size_t)threads + NH_OP_MAX_G) * sizeof(float2) + NH_OP_MAX_G * sizeof(float) + 16;
 }
@@ -1017,6 +1084,10 @@ static size_t nh_workspace_need(int N, int C, int HW, int G) {
     if (nh_geometry_onepass(N, C, HW, G, &b, &threads)) {
         const size_t n1 = nh_onepass_counter_bytes(N) + (size_t)N * b.S * G * sizeof(unsigned long long);
         if (n1 > need) need = n1;
+    }
+    if (nh_geometry_pipe(N, C, HW, G, &b, &threads)) {
+        const size_t n2 = nh_pipe_workspace(N, G, b.S);
+        if (n2 > need) need = n2;
     }
     return need;
 }
@@ -1067,8 +1138,10 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
     if (gamma != nullptr && pgn_dtype_size(affine_dtype) == 0) return PGN_ERR_INVALID;
     if (add_nc != nullptr && pgn_dtype_size(add_dtype) == 0) return PGN_ERR_INVALID;
     // `act`: bit 0 = SiLU, bits 1-3 = the caller's choice of form (PGN_GN_ONEPASS_*); NEVER and ALWAYS exclude each other
-    if ((act & ~(PGN_GN_ACT_SILU | PGN_GN_ONEPASS_NEVER | PGN_GN_ONEPASS_ALWAYS | PGN_GN_ONEPASS_NO_WAIT)) != 0 ||
-        ((act & PGN_GN_ONEPASS_NEVER) && (act & PGN_GN_ONEPASS_ALWAYS)) || !(eps >= 0.f))
+    if ((act & ~(PGN_GN_ACT_SILU | PGN_GN_ONEPASS_NEVER | PGN_GN_ONEPASS_ALWAYS | PGN_GN_ONEPASS_NO_WAIT |
+                 PGN_GN_PIPELINE_NEVER | PGN_GN_PIPELINE_ALWAYS)) != 0 ||
+        ((act & PGN_GN_ONEPASS_NEVER) && (act & PGN_GN_ONEPASS_ALWAYS)) ||
+        ((act & PGN_GN_PIPELINE_NEVER) && (act & PGN_GN_PIPELINE_ALWAYS)) || !(eps >= 0.f))
         return PGN_ERR_INVALID;
     const int form = act;
     act &= PGN_GN_ACT_SILU;
@@ -1098,6 +1171,48 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
 #endif
     hipStream_t s = (hipStream_t)stream;
     const bool has_add = add_nc != nullptr;
+    {
+        // Pipelined one-pass form (1R + 1W, persistent workgroups) for tensors ABOVE NH_OP_MAX_BYTES, where every CU is
+        // streaming and the plain one-pass form loses to the three passes: see pgn_gn_nhwc_pipe_kernel.  Needs at least
+        // one item per persistent workgroup, x and y apart.  PGN_GN_PIPELINE_NEVER / _ALWAYS override the size rule.
+        NhArgs b = a;
+        int threads1 = 0;
+        const int cus = nh_device_cus();
+        const size_t es = pgn_dtype_size(dtype);
+        const size_t yb = (size_t)N * HW * C * es, x1b = (size_t)N * HW * C1 * es, x2b = (size_t)N * HW * (C - C1) * es;
+        bool pipe = !(form & PGN_GN_PIPELINE_NEVER) && nh_geometry_pipe(N, C, HW, G, &b, &threads1) && cus > 0 &&
+                    ((form & PGN_GN_PIPELINE_ALWAYS) || (yb > NH_OP_MAX_BYTES && !(form & PGN_GN_ONEPASS_ALWAYS))) &&
+                    nh_pipe_lds(b, threads1) <= 64 * 1024 && !nh_ranges_overlap(x, x1b, y, yb) &&
+                    !(x2 != nullptr && nh_ranges_overlap(x2, x2b, y, yb));
+        // a workgroup must never hold two chunks of one sample more than one step apart (it would wait for a word it
+        // publishes itself two steps later): S <= P
+        if (pipe && (long long)b.S > ((long long)N * b.S < 2LL * cus ? (long long)N * b.S : 2LL * cus)) pipe = false;
+        if (pipe) {
+            const long long items = (long long)N * b.S;
+            const int P = (int)(items < 2LL * cus ? items : 2LL * cus);
+            b.timeout = (form & PGN_GN_ONEPASS_NO_WAIT) ? 0u : 200000u;
+            b.arrived = (unsigned int*)workspace;
+            b.stats = (float2*)((char*)workspace + nh_onepass_counter_bytes(N));
+            b.gpart = (unsigned long long*)((char*)b.stats + (size_t)N * G * 8);
+            const hipError_t me = hipMemsetAsync(workspace, 0, nh_onepass_counter_bytes(N), s);
+            if (me != hipSuccess) return (int)me;
+            const dim3 gridp((unsigned)P), blockp(threads1);
+            const size_t ldsp = nh_pipe_lds(b, threads1);
+            const int n_items = (int)items;
+#define PGN_NH_PIPE(DT)                                                                                               \
+    do {                                                                                                              \
+        if (has_add && act) hipLaunchKernelGGL((pgn_gn_nhwc_pipe_kernel<DT, true, true>), gridp, blockp, ldsp, s, b, n_items);   \
+        else if (has_add) hipLaunchKernelGGL((pgn_gn_nhwc_pipe_kernel<DT, true, false>), gridp, blockp, ldsp, s, b, n_items);    \
+        else if (act) hipLaunchKernelGGL((pgn_gn_nhwc_pipe_kernel<DT, false, true>), gridp, blockp, ldsp, s, b, n_items);        \
+        else hipLaunchKernelGGL((pgn_gn_nhwc_pipe_kernel<DT, false, false>), gridp, blockp, ldsp, s, b, n_items);                \
+    } while (0)
+            if (dtype == PGN_BF16) PGN_NH_PIPE(PGN_BF16);
+            else PGN_NH_PIPE(PGN_F16);
+#undef PGN_NH_PIPE
+            PGN_LAUNCH_CHECK();
+            return PGN_OK;
+        }
+    }
     {
         // One-pass form (1R + 1W, one launch) for tensors of up to NH_OP_MAX_BYTES: there it beats the three launches
         // (18-25 us against 28-31 us at the UNet's shapes for batches 1-4, scripts/gn_onepass_ab.py).  On larger

@@ -356,6 +356,11 @@ def _gn_nhwc_act(silu: bool) -> int:
         act |= 4
     if os.environ.get("PGN_GN_NHWC_ONEPASS_TIMEOUT", "").strip() == "0":
         act |= 8
+    pp = os.environ.get("PGN_GN_NHWC_PIPELINE", "")      # 0: three launches for large tensors too, 1: pipelined form always
+    if pp[:1] == "0":
+        act |= 16
+    elif pp[:1] == "1":
+        act |= 32
     return act
 
 

@@ -99,9 +99,10 @@ def test_argument_validation_happens_before_any_launch():
     assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 1, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 1, None, 0, None) == -1
     assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 1, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 1, p16, 8, None) == -1
     assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 0, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 1, p16, 1 << 20, None) == -2
-    # `act` is a bit set (SiLU | PGN_GN_ONEPASS_*): unknown bits and NEVER together with ALWAYS are refused
-    assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 1, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 16, p16, 1 << 20, None) == -1
+    # `act` is a bit set (SiLU | PGN_GN_ONEPASS_* | PGN_GN_PIPELINE_*): unknown bits and NEVER with ALWAYS are refused
+    assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 1, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 64, p16, 1 << 20, None) == -1
     assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 1, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 2 | 4, p16, 1 << 20, None) == -1
+    assert lib.pgn_groupnorm_silu_nhwc(p16, p16, 1, None, None, 1, None, 0, 1, 64, 16, 32, 1e-5, 16 | 32, p16, 1 << 20, None) == -1
     # concatenation form: second source mandatory, halves in multiples of 8 channels
     cat = lib.pgn_groupnorm_silu_nhwc_cat
     assert cat(p16, 32, None, 32, p16, 1, None, None, 1, None, 0, 1, 16, 32, 1e-5, 1, p16, 1 << 20, None) == -1

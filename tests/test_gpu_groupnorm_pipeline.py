@@ -1,0 +1,142 @@
+"""GPU: the pipelined one-pass channels-last GroupNorm (pgn_gn_nhwc_pipe_kernel, groupnorm_nhwc.hip) - persistent
+workgroups that publish an item's partial statistics one step before they apply them, the form tensors above 32 MiB
+take since round 3 (1 read + 1 write instead of 2 + 1; GroupNorm(+SiLU) of diffusers ResnetBlock2D /
+Transformer2DModel reached from Pigeon/models/lavit_for_pigeon.py:752-757).
+
+Checked here, through the C ABI: against the fp64 definition at the 1-ulp bar of the other forms; run-to-run bit
+identity (fixed-order merge, whoever merges); the bounded-wait safety net (wait bound 0: every workgroup computes the
+sample's statistics itself from global memory) bit-identical to the normal path; the short last chunk of a sample
+(HW not a multiple of the rows per item: the global-memory path) and samples of a single short chunk; the unwritten
+concatenation; add_nc; fp16; the refusal to run in place."""
+import os
+
+import pytest
+import torch
+
+from pigeon_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+PIPE, NEVER, NOWAIT = 32, 16 | 2, 8          # PGN_GN_PIPELINE_ALWAYS; PIPELINE_NEVER | ONEPASS_NEVER; ONEPASS_NO_WAIT
+
+
+def _call(lib, x, y, gamma, beta, add, G, eps, act, ws, x2=None):
+    N, HW, C1 = x.shape
+    dt = _lib.PGN_BF16 if x.dtype == torch.bfloat16 else _lib.PGN_F16
+    s = torch.cuda.current_stream().cuda_stream
+    ap = None if add is None else add.data_ptr()
+    if x2 is None:
+        rc = lib.pgn_groupnorm_silu_nhwc(x.data_ptr(), y.data_ptr(), dt, gamma.data_ptr(), beta.data_ptr(), dt, ap, dt,
+                                         N, C1, HW, G, eps, act, ws.data_ptr(), ws.numel(), s)
+    else:
+        rc = lib.pgn_groupnorm_silu_nhwc_cat(x.data_ptr(), C1, x2.data_ptr(), x2.shape[2], y.data_ptr(), dt,
+                                             gamma.data_ptr(), beta.data_ptr(), dt, ap, dt, N, HW, G, eps, act,
+                                             ws.data_ptr(), ws.numel(), s)
+    return rc
+
+
+def _want(x, gamma, beta, add, G, eps, silu):
+    N, HW, C = x.shape
+    xs = x if add is None else (x.float() + add.float()[:, None, :]).to(x.dtype)
+    xd = xs.double().reshape(N, HW, G, C // G)
+    mu = xd.mean(dim=(1, 3), keepdim=True)
+    var = ((xd - mu) ** 2).mean(dim=(1, 3), keepdim=True)
+    y = ((xd - mu) / torch.sqrt(var + eps)).reshape(N, HW, C) * gamma.double() + beta.double()
+    return y * torch.sigmoid(y) if silu else y
+
+
+CASES = [
+    # N, HW, C, G, add, silu, dtype
+    (3, 128 * 128, 320, 32, False, 1, torch.bfloat16),   # 96 rows per item: 171 items per sample, the last one short
+    (5, 64 * 64, 640, 32, True, 1, torch.bfloat16),      # 48 rows per item; add_nc
+    (4, 32 * 32, 1280, 32, True, 0, torch.float16),      # one row lane: 16 rows per item, every chunk full
+    (2, 76 * 52, 960, 32, False, 1, torch.bfloat16),     # 1216x832 latents: ragged
+    (7, 77, 64, 32, True, 1, torch.float16),             # HW below one item: a single SHORT chunk per sample
+    (2, 1000, 48, 6, False, 1, torch.bfloat16),          # 8 channels per group, 6 groups
+    (40, 1024, 1920, 32, False, 1, torch.bfloat16),      # more samples than a round of workgroups holds chunks of
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"N{c[0]}hw{c[1]}c{c[2]}g{c[3]}{'a' if c[4] else ''}" for c in CASES])
+def test_pipelined_form_against_fp64_safety_net_and_itself(case):
+    N, HW, C, G, with_add, silu, dtype = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(C + HW)
+    x = (torch.randn(N, HW, C, generator=g) * (0.5 + 2 * torch.rand(1, 1, C, generator=g))
+         + 2 * torch.randn(1, 1, C, generator=g)).to(dtype)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype)
+    beta = (0.2 * torch.randn(C, generator=g)).to(dtype)
+    add = (0.5 * torch.randn(N, C, generator=g)).to(dtype) if with_add else None
+    want = _want(x, gamma, beta, add, G, 1e-5, silu)
+    dx, dg, db = x.to(DEV), gamma.to(DEV), beta.to(DEV)
+    da = None if add is None else add.to(DEV)
+    ws = torch.empty(int(lib.pgn_groupnorm_nhwc_workspace_bytes(N, C, HW, G)), dtype=torch.uint8, device=DEV)
+    outs = {}
+    for name, act in (("pipe", silu | PIPE), ("again", silu | PIPE), ("net", silu | PIPE | NOWAIT), ("three", silu | NEVER)):
+        y = torch.full_like(dx, float("nan"))
+        assert _call(lib, dx, y, dg, db, da, G, 1e-5, act, ws) == 0
+        torch.cuda.synchronize()
+        outs[name] = y.cpu()
+    assert torch.equal(outs["pipe"], outs["again"])                  # deterministic whoever merges
+    assert torch.equal(outs["pipe"], outs["net"])                    # the safety net computes the same words
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    for name in ("pipe", "three"):
+        err = (outs[name].double() - want).abs()
+        assert bool((err <= ulp * want.abs() + 4 * ulp * 2.0 ** -7 + 1e-6).all()), (name, err.max().item())
+    assert (outs["pipe"] != outs["three"]).float().mean().item() < 0.01   # two summation orders: last-bit noise only
+
+
+def test_pipelined_form_over_an_unwritten_concatenation_and_never_in_place():
+    lib = _lib.load()
+    N, HW, C1, C2, G = 3, 64 * 64, 640, 320, 32
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(N, HW, C1 + C2, generator=g) * 1.5 + torch.randn(1, 1, C1 + C2, generator=g)).bfloat16()
+    gamma = (1 + 0.2 * torch.randn(C1 + C2, generator=g)).bfloat16().to(DEV)
+    beta = (0.2 * torch.randn(C1 + C2, generator=g)).bfloat16().to(DEV)
+    dx = x.to(DEV)
+    d1, d2 = dx[..., :C1].contiguous(), dx[..., C1:].contiguous()
+    ws = torch.empty(int(lib.pgn_groupnorm_nhwc_workspace_bytes(N, C1 + C2, HW, G)), dtype=torch.uint8, device=DEV)
+    y_cat, y_one, y_three = torch.empty_like(dx), torch.empty_like(dx), torch.empty_like(dx)
+    assert _call(lib, d1, y_cat, gamma, beta, None, G, 1e-5, 1 | PIPE, ws, x2=d2) == 0
+    assert _call(lib, dx, y_one, gamma, beta, None, G, 1e-5, 1 | PIPE, ws) == 0
+    assert _call(lib, dx, y_three, gamma, beta, None, G, 1e-5, 1 | NEVER, ws) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y_cat, y_one)
+    # y == x: peers re-read rows in the safety net, so the pipelined form must not be picked; the three launches are
+    inplace = dx.clone()
+    assert _call(lib, inplace, inplace, gamma, beta, None, G, 1e-5, 1 | PIPE, ws) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(inplace, y_three)
+
+
+def test_pipelined_form_is_what_large_tensors_take_and_one_workspace_serves_back_to_back_calls():
+    """Default rule (no flag): a 64 MiB tensor runs the pipelined form (bit-equal to the forced run), a 16 MiB one does
+    not.  Six calls share one workspace without synchronisation: the counters are zeroed by the call itself."""
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(1)
+    big = (torch.randn(8, 128 * 128, 256, generator=g, device=DEV) * 1.3 + 0.5).bfloat16()      # 64 MiB
+    small = big[:2].contiguous()                                                                  # 16 MiB
+    dg = (1 + 0.2 * torch.randn(256, generator=g, device=DEV)).bfloat16()
+    db = (0.2 * torch.randn(256, generator=g, device=DEV)).bfloat16()
+    ws = torch.empty(int(lib.pgn_groupnorm_nhwc_workspace_bytes(8, 256, 128 * 128, 32)), dtype=torch.uint8, device=DEV)
+    outs = []
+    for x, act in ((big, 1), (big, 1 | PIPE), (small, 1), (small, 1 | PIPE), (big, 1), (big, 1 | PIPE | NOWAIT)):
+        y = torch.full_like(x, float("nan"))
+        assert _call(lib, x, y, dg, db, None, 32, 1e-5, act, ws) == 0
+        outs.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[4], outs[1]) and torch.equal(outs[5], outs[1])
+    assert not torch.equal(outs[2], outs[3])          # 16 MiB: the plain one-pass form by default (other chunking)
+    assert (outs[2] != outs[3]).float().mean().item() < 0.01
+    # through the Python binding: the UNet's largest tensor class
+    xc = big.reshape(8, 128, 128, 256).permute(0, 3, 1, 2)       # channels_last view
+    assert torch.equal(ops.group_norm_silu(xc, 32, dg, db, 1e-5, True).permute(0, 2, 3, 1).reshape(8, -1, 256), outs[0])
+
+
+def test_flag_validation_needs_no_launch():
+    lib = _lib.load()
+    x = torch.zeros(1, 64, 64, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    gb = torch.ones(64, dtype=torch.bfloat16, device=DEV)
+    assert _call(lib, x, torch.empty_like(x), gb, gb, None, 32, 1e-5, 1 | 16 | 32, ws) == -1     # NEVER and ALWAYS
+    assert _call(lib, x, torch.empty_like(x), gb, gb, None, 32, 1e-5, 64, ws) == -1              # unknown bit
