@@ -187,8 +187,9 @@ int pgn_groupnorm_silu_ex(const void* x, int x_dtype, void* y, int y_dtype, cons
 #define PGN_GN_ONEPASS_NEVER 2
 #define PGN_GN_ONEPASS_ALWAYS 4
 #define PGN_GN_ONEPASS_NO_WAIT 8
-#define PGN_GN_PIPELINE_NEVER 16  /* tensors above 32 MiB: keep the three launches (default: the pipelined one-pass form) */
-#define PGN_GN_PIPELINE_ALWAYS 32 /* take the pipelined one-pass form at any size the shape allows (tests, measurements) */
+#define PGN_GN_PIPELINE_NEVER 16  /* accepted and ignored by the shipped library (see the next line) */
+#define PGN_GN_PIPELINE_ALWAYS 32 /* measurement build only: the pipelined persistent one-pass form (slower than the three
+                                     launches); the shipped library accepts the bit and ignores it */
 size_t pgn_groupnorm_nhwc_workspace_bytes(int N, int C, int HW, int G);
 int pgn_groupnorm_silu_nhwc(const void* x, void* y, int dtype, const void* gamma, const void* beta, int affine_dtype,
                             const void* add_nc, int add_dtype, int N, int C, int HW, int G, float eps, int act,

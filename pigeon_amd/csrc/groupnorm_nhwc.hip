@@ -613,8 +613,15 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_onepass_kernel(NhA
 #undef NH_STAMP
 }
 
+#ifdef PGN_TUNING_HOOKS
 // ---------------------------------------------------------------------------------------------------------------------
 // Pipelined one-pass form for LARGE tensors (round 3; 1 read + 1 write like the form above).
+// MEASURED NEGATIVE, measurement build only (PGN_GN_PIPELINE_ALWAYS in `act` selects it there): correct (its tests pass:
+// fp64 bar, bit-identical safety net, concatenation, short chunks), traffic 1.0x, but 0.35-0.49x the speed of the three
+// launches at UNet batch 32 (1.2-1.7 against 3.4 TB/s algorithmic; profiles/r03_groupnorm_pipeline_ab.txt) and 0.2-0.3x
+// with four smaller workgroups per CU.  A step chains five or six global round trips that nothing overlaps at two
+// workgroups per CU (publish + drain, fetch_add with its result, first poll, acquire, statistics load, then the exposed
+// row loads), ~40 us per 61 KB item; the three launches stream with none.  The text below is the design as built.
 // Why the form above loses on a saturated chip (batch 32: 0.70-0.87x of the three passes): between publishing its
 // partial statistics and applying them a workgroup WAITS for the slowest workgroup of its sample (median 21 us of a
 // 47 us life, scripts/gn_wg_timeline.py) with its rows parked in registers and nothing in flight.  Here the wait is
@@ -632,9 +639,14 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_onepass_kernel(NhA
 // wait is bounded, and a workgroup whose wait runs out computes the sample's statistics itself (all chunks from
 // global memory, same arithmetic, same order).  x and y must not overlap.
 constexpr int NH_PP_ROWS = 16;
+constexpr long long NH_PP_WGS_PER_CU = 2;
 
 template <int DT, bool HAS_ADD, bool ACT>
 __global__ __launch_bounds__(256, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int n_items) {
+    // No FMA contraction in this kernel: a chunk's word is computed by two differently shaped copies of the same
+    // arithmetic (rows in registers; rows from global memory in the safety net and for a short last chunk), and the
+    // merge is inlined twice; the words must not depend on which copy the compiler chose to contract.
+#pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float2 sh[];
     float* shf = reinterpret_cast<float*>(sh);                            // [R][C] lane sums
     float2* shL = reinterpret_cast<float2*>(shf + (size_t)a.R * a.C);     // [threads] chunk-lane partial merges
@@ -991,6 +1003,8 @@ __global__ __launch_bounds__(256, 2) void pgn_gn_nhwc_pipe_kernel(NhArgs a, int 
     }
 }
 
+#endif  // PGN_TUNING_HOOKS (pgn_gn_nhwc_pipe_kernel)
+
 static size_t nh_onepass_counter_bytes_fwd(int N) { return (((size_t)N * sizeof(unsigned int)) + 255) & ~(size_t)255; }
 
 // workgroups aimed at per launch, minimum rows per lane: swept on MI355X (scripts/gn_exp.py): fewer, longer workgroups
@@ -1041,6 +1055,7 @@ static bool nh_geometry_onepass(int N, int C, int HW, int G, NhArgs* a, int* thr
     return (long long)N * a->S <= 0x7fffffffLL;
 }
 
+#ifdef PGN_TUNING_HOOKS
 // pipelined form: workgroups of at most 256 threads (two per CU at 256 VGPRs: two items of NH_PP_ROWS rows per lane in
 // registers and room for the phases' working set - at 512 threads / 128 VGPRs the persistent loop spilled a whole item)
 static bool nh_geometry_pipe(int N, int C, int HW, int G, NhArgs* a, int* threads) {
@@ -1066,6 +1081,7 @@ static size_t nh_pipe_lds(const NhArgs& a, int threads) {
 static size_t nh_pipe_workspace(int N, int G, int S) {
     return nh_onepass_counter_bytes_fwd(N) + (size_t)N * G * 8 + (size_t)N * S * G * 8;
 }
+#endif
 
 static size_t nh_onepass_lds(const NhArgs& a, int threads) {
     return ((size_t)a.R * a.C + (size_t)threads + NH_OP_MAX_G) * sizeof(float2) + NH_OP_MAX_G * sizeof(float) + 16;
@@ -1085,10 +1101,12 @@ static size_t nh_workspace_need(int N, int C, int HW, int G) {
         const size_t n1 = nh_onepass_counter_bytes(N) + (size_t)N * b.S * G * sizeof(unsigned long long);
         if (n1 > need) need = n1;
     }
+#ifdef PGN_TUNING_HOOKS
     if (nh_geometry_pipe(N, C, HW, G, &b, &threads)) {
         const size_t n2 = nh_pipe_workspace(N, G, b.S);
         if (n2 > need) need = n2;
     }
+#endif
     return need;
 }
 
@@ -1171,25 +1189,26 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
 #endif
     hipStream_t s = (hipStream_t)stream;
     const bool has_add = add_nc != nullptr;
+#ifdef PGN_TUNING_HOOKS
     {
-        // Pipelined one-pass form (1R + 1W, persistent workgroups) for tensors ABOVE NH_OP_MAX_BYTES, where every CU is
-        // streaming and the plain one-pass form loses to the three passes: see pgn_gn_nhwc_pipe_kernel.  Needs at least
-        // one item per persistent workgroup, x and y apart.  PGN_GN_PIPELINE_NEVER / _ALWAYS override the size rule.
+        // Pipelined one-pass form (1R + 1W, persistent workgroups): measurement build only, and only on request
+        // (PGN_GN_PIPELINE_ALWAYS) - it measured 0.35-0.49x of the three launches: see pgn_gn_nhwc_pipe_kernel.
         NhArgs b = a;
         int threads1 = 0;
         const int cus = nh_device_cus();
         const size_t es = pgn_dtype_size(dtype);
         const size_t yb = (size_t)N * HW * C * es, x1b = (size_t)N * HW * C1 * es, x2b = (size_t)N * HW * (C - C1) * es;
         bool pipe = !(form & PGN_GN_PIPELINE_NEVER) && nh_geometry_pipe(N, C, HW, G, &b, &threads1) && cus > 0 &&
-                    ((form & PGN_GN_PIPELINE_ALWAYS) || (yb > NH_OP_MAX_BYTES && !(form & PGN_GN_ONEPASS_ALWAYS))) &&
+                    (form & PGN_GN_PIPELINE_ALWAYS) &&
                     nh_pipe_lds(b, threads1) <= 64 * 1024 && !nh_ranges_overlap(x, x1b, y, yb) &&
                     !(x2 != nullptr && nh_ranges_overlap(x2, x2b, y, yb));
         // a workgroup must never hold two chunks of one sample more than one step apart (it would wait for a word it
         // publishes itself two steps later): S <= P
-        if (pipe && (long long)b.S > ((long long)N * b.S < 2LL * cus ? (long long)N * b.S : 2LL * cus)) pipe = false;
+        const long long resident = NH_PP_WGS_PER_CU * cus;
+        if (pipe && (long long)b.S > ((long long)N * b.S < resident ? (long long)N * b.S : resident)) pipe = false;
         if (pipe) {
             const long long items = (long long)N * b.S;
-            const int P = (int)(items < 2LL * cus ? items : 2LL * cus);
+            const int P = (int)(items < resident ? items : resident);
             b.timeout = (form & PGN_GN_ONEPASS_NO_WAIT) ? 0u : 200000u;
             b.arrived = (unsigned int*)workspace;
             b.stats = (float2*)((char*)workspace + nh_onepass_counter_bytes(N));
@@ -1213,6 +1232,7 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
             return PGN_OK;
         }
     }
+#endif
     {
         // One-pass form (1R + 1W, one launch) for tensors of up to NH_OP_MAX_BYTES: there it beats the three launches
         // (18-25 us against 28-31 us at the UNet's shapes for batches 1-4, scripts/gn_onepass_ab.py).  On larger

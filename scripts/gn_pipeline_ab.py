@@ -3,7 +3,9 @@
 shapes (B = UNet batch, default 32 = the bench configuration): interleaved rounds in one process, HIP events, best of
 3 x 20 calls; with and without the per-(sample, channel) addend of ResnetBlock2D's norm2."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _tuning_lib import use_tuning_lib
+use_tuning_lib()          # the pipelined form exists in the measurement build only (make -C pigeon_amd/csrc tuning)
 import torch
 from pigeon_amd import ops
 

@@ -1,7 +1,11 @@
 """GPU: the pipelined one-pass channels-last GroupNorm (pgn_gn_nhwc_pipe_kernel, groupnorm_nhwc.hip) - persistent
-workgroups that publish an item's partial statistics one step before they apply them, the form tensors above 32 MiB
-take since round 3 (1 read + 1 write instead of 2 + 1; GroupNorm(+SiLU) of diffusers ResnetBlock2D /
-Transformer2DModel reached from Pigeon/models/lavit_for_pigeon.py:752-757).
+workgroups that publish an item's partial statistics one step before they apply them (1 read + 1 write instead of
+2 + 1; GroupNorm(+SiLU) of diffusers ResnetBlock2D / Transformer2DModel reached from
+Pigeon/models/lavit_for_pigeon.py:752-757).  A MEASURED NEGATIVE of round 3 (0.35-0.49x of the three launches at UNet
+batch 32): the kernel lives in the MEASUREMENT build only (make -C pigeon_amd/csrc tuning) and runs only
+on request, so this file drives libpigeon_hip_tuning.so through its own ctypes handle (the product library stays the
+one every other test loads) and is skipped when that build is absent.  The kernel stays tested so that its numbers can
+be re-measured on a correct kernel.
 
 Checked here, through the C ABI: against the fp64 definition at the 1-ulp bar of the other forms; run-to-run bit
 identity (fixed-order merge, whoever merges); the bounded-wait safety net (wait bound 0: every workgroup computes the
@@ -13,10 +17,27 @@ import os
 import pytest
 import torch
 
-from pigeon_amd import _lib, ops
+import ctypes
+
+from pigeon_amd import _lib
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+TUNING_LIB = os.path.join(os.path.dirname(_lib.LIB_PATH), "libpigeon_hip_tuning.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(TUNING_LIB):
+        pytest.skip("measurement build absent (make -C pigeon_amd/csrc tuning)")
+    import torch  # noqa: F401  (the HIP runtime first, as _lib.load does)
+    h = ctypes.CDLL(TUNING_LIB)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(h, name)
+        fn.restype = res
+        fn.argtypes = args
+    return h
+
 PIPE, NEVER, NOWAIT = 32, 16 | 2, 8          # PGN_GN_PIPELINE_ALWAYS; PIPELINE_NEVER | ONEPASS_NEVER; ONEPASS_NO_WAIT
 
 
@@ -58,9 +79,8 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"N{c[0]}hw{c[1]}c{c[2]}g{c[3]}{'a' if c[4] else ''}" for c in CASES])
-def test_pipelined_form_against_fp64_safety_net_and_itself(case):
+def test_pipelined_form_against_fp64_safety_net_and_itself(lib, case):
     N, HW, C, G, with_add, silu, dtype = case
-    lib = _lib.load()
     g = torch.Generator().manual_seed(C + HW)
     x = (torch.randn(N, HW, C, generator=g) * (0.5 + 2 * torch.rand(1, 1, C, generator=g))
          + 2 * torch.randn(1, 1, C, generator=g)).to(dtype)
@@ -86,8 +106,7 @@ def test_pipelined_form_against_fp64_safety_net_and_itself(case):
     assert (outs["pipe"] != outs["three"]).float().mean().item() < 0.01   # two summation orders: last-bit noise only
 
 
-def test_pipelined_form_over_an_unwritten_concatenation_and_never_in_place():
-    lib = _lib.load()
+def test_pipelined_form_over_an_unwritten_concatenation_and_never_in_place(lib):
     N, HW, C1, C2, G = 3, 64 * 64, 640, 320, 32
     g = torch.Generator().manual_seed(5)
     x = (torch.randn(N, HW, C1 + C2, generator=g) * 1.5 + torch.randn(1, 1, C1 + C2, generator=g)).bfloat16()
@@ -109,32 +128,26 @@ def test_pipelined_form_over_an_unwritten_concatenation_and_never_in_place():
     assert torch.equal(inplace, y_three)
 
 
-def test_pipelined_form_is_what_large_tensors_take_and_one_workspace_serves_back_to_back_calls():
-    """Default rule (no flag): a 64 MiB tensor runs the pipelined form (bit-equal to the forced run), a 16 MiB one does
-    not.  Six calls share one workspace without synchronisation: the counters are zeroed by the call itself."""
-    lib = _lib.load()
+def test_one_workspace_serves_back_to_back_calls_and_the_default_rule_never_picks_the_form(lib):
+    """Six calls share one workspace without synchronisation (the counters are zeroed by the call itself).  Without the
+    request bit the three launches run whatever the size: the form is a measurement, not a default."""
     g = torch.Generator(device=DEV).manual_seed(1)
     big = (torch.randn(8, 128 * 128, 256, generator=g, device=DEV) * 1.3 + 0.5).bfloat16()      # 64 MiB
-    small = big[:2].contiguous()                                                                  # 16 MiB
     dg = (1 + 0.2 * torch.randn(256, generator=g, device=DEV)).bfloat16()
     db = (0.2 * torch.randn(256, generator=g, device=DEV)).bfloat16()
     ws = torch.empty(int(lib.pgn_groupnorm_nhwc_workspace_bytes(8, 256, 128 * 128, 32)), dtype=torch.uint8, device=DEV)
     outs = []
-    for x, act in ((big, 1), (big, 1 | PIPE), (small, 1), (small, 1 | PIPE), (big, 1), (big, 1 | PIPE | NOWAIT)):
-        y = torch.full_like(x, float("nan"))
-        assert _call(lib, x, y, dg, db, None, 32, 1e-5, act, ws) == 0
+    for act in (1 | PIPE, 1, 1 | PIPE, 1 | NEVER, 1 | PIPE | NOWAIT, 1 | PIPE):
+        y = torch.full_like(big, float("nan"))
+        assert _call(lib, big, y, dg, db, None, 32, 1e-5, act, ws) == 0
         outs.append(y)
     torch.cuda.synchronize()
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[4], outs[1]) and torch.equal(outs[5], outs[1])
-    assert not torch.equal(outs[2], outs[3])          # 16 MiB: the plain one-pass form by default (other chunking)
-    assert (outs[2] != outs[3]).float().mean().item() < 0.01
-    # through the Python binding: the UNet's largest tensor class
-    xc = big.reshape(8, 128, 128, 256).permute(0, 3, 1, 2)       # channels_last view
-    assert torch.equal(ops.group_norm_silu(xc, 32, dg, db, 1e-5, True).permute(0, 2, 3, 1).reshape(8, -1, 256), outs[0])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[4]) and torch.equal(outs[0], outs[5])
+    assert torch.equal(outs[1], outs[3])                           # no request bit = the three launches
+    assert not torch.equal(outs[0], outs[1]) and (outs[0] != outs[1]).float().mean().item() < 0.01
 
 
-def test_flag_validation_needs_no_launch():
-    lib = _lib.load()
+def test_flag_validation_needs_no_launch(lib):
     x = torch.zeros(1, 64, 64, dtype=torch.bfloat16, device=DEV)
     ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
     gb = torch.ones(64, dtype=torch.bfloat16, device=DEV)
