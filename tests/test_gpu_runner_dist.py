@@ -80,10 +80,15 @@ def pipe_run(pipe, tokens, labels, uids, genres, targets, history, folder, **kw)
 
 
 def _rank_main(rank, world, port, tmp):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      RANK=str(rank), LOCAL_RANK=str(rank))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pigeon_amd import _lib
+        # the ranks of a multi-process job read a PRIVATE copy of the in-tree MIOpen find-db
+        # (pigeon_amd/__init__.py; the parent spawned us with WORLD_SIZE set and no MIOPEN_USER_DB_PATH)
+        assert "pigeon_miopen_db_r" in os.environ["MIOPEN_USER_DB_PATH"], os.environ["MIOPEN_USER_DB_PATH"]
+        assert any(f.endswith(".ufdb.txt") for f in os.listdir(os.environ["MIOPEN_USER_DB_PATH"]))
         pipe = _build_pipe()
         res, sel, lat = _run(pipe, os.path.join(tmp, "w2"), rank=rank, world_size=world, seed=SEED)
         assert "pigeon_amd/lib/libpigeon_hip.so" in open("/proc/self/maps").read() and _lib.load() is not None
@@ -130,7 +135,17 @@ def test_runner_on_the_real_pipeline_one_rank_then_two(tmp_path):
 
     # (b) two ranks on the one device
     port = _free_port()
-    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    saved = {k: os.environ.get(k) for k in ("MIOPEN_USER_DB_PATH", "WORLD_SIZE")}
+    os.environ.pop("MIOPEN_USER_DB_PATH", None)      # what a launcher's fresh rank processes see: WORLD_SIZE, no db path yet
+    os.environ["WORLD_SIZE"] = "2"
+    try:
+        mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     outs = [torch.load(tmp_path / f"out_rank{r}.pt") for r in range(2)]
     assert torch.equal(outs[0][2], outs[1][2]) and outs[0][1] == outs[1][1]        # every rank holds the same gather
     lat2 = outs[0][2]
