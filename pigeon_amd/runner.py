@@ -39,9 +39,9 @@ def all_gather_results(latents: torch.Tensor, scores: Optional[torch.Tensor], co
     one fp32 row [4*h*w + S] (latents, then its scores), uneven tails are padded to max(counts) rows for the collective
     and trimmed afterwards.  Works with backend nccl (RCCL over xGMI) and gloo.  Returns (latents, scores | None) in
     global (rank-major = task) order, on the device the inputs live on."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return latents, scores
+    world = dist.get_world_size(group)      # a one-rank group still goes through the collective (RCCL rehearsal)
     if latents.shape[0] != counts[dist.get_rank(group)] or (scores is not None and scores.shape[0] != latents.shape[0]):
         raise ValueError("all_gather_results: row counts do not match this rank's entry of `counts`")
     m = max(counts)
