@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PGN_VERSION 111 /* 0.1.2: the channels-last GroupNorm entries take their choice of form as bits of `act` (the library reads no environment); 0.1.1: + pgn_token_embed, pgn_attention_causal_fwd, pgn_groupnorm_silu_nhwc_static */
+#define PGN_VERSION 112 /* 0.1.3: + pgn_bias_residual_add_stats, pgn_groupnorm_silu_nhwc_pre (GroupNorm statistics emitted by the launch that produces the tensor); 0.1.2: the channels-last GroupNorm entries take their choice of form as bits of `act` (the library reads no environment); 0.1.1: + pgn_token_embed, pgn_attention_causal_fwd, pgn_groupnorm_silu_nhwc_static */
 
 #define PGN_OK 0
 #define PGN_ERR_INVALID (-1)     /* null pointer, non-positive size, bad enum, misalignment */
@@ -207,6 +207,18 @@ int pgn_groupnorm_silu_nhwc_cat(const void* x1, int C1, const void* x2, int C2, 
                                 const void* beta, int affine_dtype, const void* add_nc, int add_dtype, int N, int HW,
                                 int G, float eps, int act, void* workspace, size_t workspace_bytes, void* stream);
 
+/* pgn_groupnorm_silu_nhwc / _cat for inputs that come with the partial statistics of their producer
+ * (pgn_bias_residual_add_stats): part1 belongs to x1 [N, HW, C1], part2 to x2 [N, HW, C2] (x2 = part2 = NULL and
+ * C2 = 0 for a single input; with two inputs both must bring partials).  Two launches (per-group mean / rstd from the
+ * partials, apply): the tensor is read once and written once.  For a single input the result is bit-identical to
+ * pgn_groupnorm_silu_nhwc's three-launch form (same words, same order); for a concatenation the halves' chunkings
+ * differ from the concatenation's own, so mean / rstd agree to fp32 rounding and outputs to <= 1 unit in the last
+ * place of the 16-bit type.  No add_nc (the partials describe the tensor as stored).  act: 0 or PGN_GN_ACT_SILU.
+ * workspace: at least N * G * 8 bytes, 8-byte aligned.  Same reference call sites as pgn_groupnorm_silu_nhwc / _cat. */
+int pgn_groupnorm_silu_nhwc_pre(const void* x1, int C1, const void* part1, const void* x2, int C2, const void* part2,
+                                void* y, int dtype, const void* gamma, const void* beta, int affine_dtype, int N, int HW,
+                                int G, float eps, int act, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Allocation-free variant of pgn_groupnorm_silu_nhwc.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
  * cannot allocate device memory around the call — code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  Same kernels, arithmetic and results (bit-identical) as pgn_groupnorm_silu_nhwc; the
@@ -329,6 +341,24 @@ int pgn_clip_scores(const void* img_feat, int img_dtype, int64_t img_ld, const v
  */
 int pgn_bias_residual_add(const void* x, const void* residual, const void* bias, int bias_dtype, void* y, int dtype,
                           int64_t rows, int C, int64_t inner, void* stream);
+
+/* The same add for a CHANNELS-LAST activation [N, HW, C] whose consumer is a channels-last GroupNorm, emitting that
+ * GroupNorm's partial statistics in the same pass: y as pgn_bias_residual_add writes it (bit-identical), and `part`
+ * [N][S][C] pairs of floats — per (sample, row chunk, channel) the pivot-shifted sum and sum of squares of y that the
+ * first of pgn_groupnorm_silu_nhwc's three launches would otherwise compute by reading y back (bit-identical words:
+ * same chunking, a function of (N, C, HW) alone, same pivots, same order).  Same reference lines as
+ * pgn_bias_residual_add; what it additionally replaces is the statistics read of `self.norm1(hidden_states)` /
+ * Transformer2DModel's `self.norm(hidden_states)` in the module that consumes y (diffusers 0.27.2 ResnetBlock2D.forward,
+ * Transformer2DModel.forward, reached from lavit_for_pigeon.py:752-757): GroupNorm's traffic on such a tensor falls
+ * from 2 reads + 1 write to 1 + 1.
+ * pgn_bias_residual_add_stats_bytes: bytes of `part` for the shape, or 0 when the form does not apply (C % 8 != 0 or
+ * C > 8192: use pgn_bias_residual_add).  It pays for tensors above 32 MiB; smaller ones the consuming GroupNorm takes
+ * in ONE launch without partials (that rule is the caller's: pigeon_amd/ops.py GN_STATS_MIN_BYTES).  y must overlap neither x nor residual (every workgroup of a sample reads three pivot
+ * rows of the inputs); bias 16-byte aligned; `part` 8-byte aligned, contents irrelevant on entry.  bf16 / f16.
+ * Algorithmic bytes as pgn_bias_residual_add (+ N*S*C*8 for the partials, < 1 % of the tensor). */
+size_t pgn_bias_residual_add_stats_bytes(int N, int C, int HW);
+int pgn_bias_residual_add_stats(const void* x, const void* residual, const void* bias, int bias_dtype, void* y,
+                                int dtype, int N, int C, int HW, void* part, size_t part_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (residual add +) LayerNorm over the last dimension, one pass.

@@ -42,6 +42,10 @@ SIGNATURES = {
     "pgn_geglu": (_i, [_vp, _vp, _i, _i64, _i, _i64, _i64, _vp]),
     "pgn_clip_scores": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp]),
     "pgn_bias_residual_add": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i64, _vp]),
+    "pgn_bias_residual_add_stats_bytes": (_c.c_size_t, [_i, _i, _i]),
+    "pgn_bias_residual_add_stats": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _c.c_size_t, _vp]),
+    "pgn_groupnorm_silu_nhwc_pre": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp,
+                                         _c.c_size_t, _vp]),
     "pgn_add_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _f, _vp]),
     "pgn_add_layernorm_cb": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _f, _vp]),
     "pgn_image_to_uint8": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),

@@ -44,6 +44,11 @@ struct NhArgs {
     int reverse;     // apply pass: walk the workgroups from the last row chunk of the last sample to the first
     float2* part;    // [N][S][C]
     float2* stats;   // [N][G]
+    // what the finalize launch reads: `part` as [N][partS][partC] for channels [0, partC); channels [partC, C) from
+    // `part2` as [N][part2S][C - partC] when the two halves of a concatenation bring their own partials
+    // (pgn_groupnorm_silu_nhwc_pre), else part2 == nullptr, partS == S, partC == C
+    const float2* part2;
+    int partS, partC, part2S;
     // one-pass form only
     unsigned int* arrived;           // [N] workgroups of the sample that have published (zeroed by the launch function)
     unsigned long long* gpart;       // [N][S][G] {sum, sum of squares} about the group pivot, one 8-byte word each
@@ -108,6 +113,24 @@ __device__ __forceinline__ float nh_silu(float v) {
 // as run-time flags they were if-converted into ~110 v_cndmask per loop body.  The per-element arithmetic is written on
 // float pairs so that it compiles to packed fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma: two elements per issue
 // slot); the operations and their order are unchanged, results are bit-identical to the scalar form.
+// one 16-byte vector of a lane's column into its pivot-shifted sums: shared by the statistics launch and by the
+// producer-side form (pgn_bias_res_stats_kernel), whose words must be the statistics launch's bit for bit
+template <int DT, bool HAS_ADD>
+__device__ __forceinline__ void nh_accum8(const u16x8_t& v, const float (&tadd)[8], const float (&piv)[8], f32x2_t (&s2)[4],
+                                          f32x2_t (&q2)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f32x2_t f = {Cvt<DT>::to_f32(v[2 * p]), Cvt<DT>::to_f32(v[2 * p + 1])};
+        if constexpr (HAS_ADD) {
+            f += f32x2_t{tadd[2 * p], tadd[2 * p + 1]};
+            f = f32x2_t{Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[0])), Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[1]))};
+        }
+        const f32x2_t d = f - f32x2_t{piv[2 * p], piv[2 * p + 1]};
+        s2[p] += d;
+        q2[p] += d * d;
+    }
+}
+
 template <int DT, bool HAS_ADD>
 __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArgs a) {
     extern __shared__ float2 sh[];   // [R][C]
@@ -139,19 +162,7 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArg
             for (int j = 0; j < 8; ++j) piv[j] = __builtin_amdgcn_fmed3f(piv[j], pa[j], pb[j]);
         }
         const int row1 = min(a.HW, (sc + 1) * a.rows);
-        auto accum = [&](const u16x8_t& v) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                f32x2_t f = {Cvt<DT>::to_f32(v[2 * p]), Cvt<DT>::to_f32(v[2 * p + 1])};
-                if constexpr (HAS_ADD) {
-                    f += f32x2_t{tadd[2 * p], tadd[2 * p + 1]};
-                    f = f32x2_t{Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[0])), Cvt<DT>::to_f32(Cvt<DT>::from_f32(f[1]))};
-                }
-                const f32x2_t d = f - f32x2_t{piv[2 * p], piv[2 * p + 1]};
-                s2[p] += d;
-                q2[p] += d * d;
-            }
-        };
+        auto accum = [&](const u16x8_t& v) { nh_accum8<DT, HAS_ADD>(v, tadd, piv, s2, q2); };
         int row = sc * a.rows + r;
         // four independent 16-byte loads in flight per lane (a lane's rows are R rows apart)
         for (; row + 3 * a.R < row1; row += 4 * a.R) {
@@ -162,6 +173,94 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_stats_kernel(NhArg
             accum(v0); accum(v1); accum(v2); accum(v3);
         }
         for (; row < row1; row += a.R) accum(*reinterpret_cast<const u16x8_t*>(xp + (size_t)row * pitch));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[(size_t)r * a.C + cc * 8 + j] = make_float2(s2[j >> 1][j & 1], q2[j >> 1][j & 1]);
+    }
+    __syncthreads();
+    for (int c = t; c < a.C; c += blockDim.x) {
+        float ss = 0.f, qq = 0.f;
+        for (int rr = 0; rr < a.R; ++rr) {
+            const float2 v = sh[(size_t)rr * a.C + c];
+            ss += v.x;
+            qq += v.y;
+        }
+        a.part[((size_t)n * a.S + sc) * a.C + c] = make_float2(ss, qq);
+    }
+}
+
+// Producer-side statistics (pgn_bias_residual_add_stats): y = round(round(x + bias[c]) + res), the arithmetic of
+// pgn_bias_res_cl_kernel, on the statistics launch's workgroup geometry, and the per-(sample, row chunk, channel)
+// partials of y in the same pass - the words pgn_gn_nhwc_stats_kernel<DT, false> would write after reading y back
+// (same pivots: median of y's rows 0, HW / 2, HW - 1, recomputed here from the inputs; same order of accumulation).
+// The GroupNorm that consumes y then starts at its finalize launch: its first read of the tensor is gone.  x (and res)
+// must not overlap y: every workgroup of a sample reads the three pivot rows of the INPUTS.
+// U rows in flight per lane, WPS waves per SIMD the register budget is cut for (measured: see the launch function)
+template <int DT, bool HAS_RES, int U, int WPS>
+__global__ __launch_bounds__(NH_MAX_THREADS, WPS) void pgn_bias_res_stats_kernel(NhArgs a, const void* __restrict__ res,
+                                                                               const void* __restrict__ bias, int bdt) {
+    extern __shared__ float2 sh[];   // [R][C]
+    const int n = blockIdx.x / a.S, sc = blockIdx.x % a.S;
+    const int t = threadIdx.x;
+    const int r = t / a.C8, cc = t - r * a.C8;
+    const bool active = r < a.R;
+    if (active) {
+        float b[8], piv[8], none[8];
+        f32x2_t s2[4], q2[4];
+        nh_param8(bias, bdt, (size_t)cc * 8, 0.f, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) none[j] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { s2[p] = f32x2_t{0.f, 0.f}; q2[p] = f32x2_t{0.f, 0.f}; }
+        const size_t col = (size_t)n * a.HW * a.C + (size_t)cc * 8;
+        const unsigned short* xp = reinterpret_cast<const unsigned short*>(a.x) + col;
+        const unsigned short* rp = reinterpret_cast<const unsigned short*>(res) + col;
+        unsigned short* yp = reinterpret_cast<unsigned short*>(a.y) + col;
+        auto produce = [&](const u16x8_t& vx, const u16x8_t& vr) {
+            u16x8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = Cvt<DT>::to_f32(Cvt<DT>::from_f32(Cvt<DT>::to_f32(vx[j]) + b[j]));
+                if constexpr (HAS_RES) f += Cvt<DT>::to_f32(vr[j]);
+                o[j] = Cvt<DT>::from_f32(f);
+            }
+            return o;
+        };
+        auto ldx = [&](size_t row) { return *reinterpret_cast<const u16x8_t*>(xp + row * a.C); };
+        auto ldr = [&](size_t row) {
+            if constexpr (HAS_RES) return *reinterpret_cast<const u16x8_t*>(rp + row * a.C);
+            else return u16x8_t{};
+        };
+        {
+            const size_t rows3[3] = {0, (size_t)(a.HW / 2), (size_t)(a.HW - 1)};
+            float pv[3][8];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const u16x8_t o = produce(ldx(rows3[k]), ldr(rows3[k]));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[k][j] = Cvt<DT>::to_f32(o[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) piv[j] = __builtin_amdgcn_fmed3f(pv[0][j], pv[1][j], pv[2][j]);
+        }
+        const int row1 = min(a.HW, (sc + 1) * a.rows);
+        auto one = [&](const u16x8_t& vx, const u16x8_t& vr, size_t row) {
+            const u16x8_t o = produce(vx, vr);
+            *reinterpret_cast<u16x8_t*>(yp + row * a.C) = o;
+            nh_accum8<DT, false>(o, none, piv, s2, q2);
+        };
+        int row = sc * a.rows + r;
+        // two rows (four 16-byte loads with a residual) in flight per lane: at <= 64 VGPRs two 1024-thread workgroups
+        // share a CU, so one streams while the other is in its LDS reduction (four rows: 123 VGPRs, one workgroup)
+        for (; row + (U - 1) * a.R < row1; row += U * a.R) {
+            u16x8_t xv[U], rv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = ldx(row + u * a.R);
+#pragma unroll
+            for (int u = 0; u < U; ++u) rv[u] = ldr(row + u * a.R);
+#pragma unroll
+            for (int u = 0; u < U; ++u) one(xv[u], rv[u], row + u * a.R);
+        }
+        for (; row < row1; row += a.R) one(ldx(row), ldr(row), row);
 #pragma unroll
         for (int j = 0; j < 8; ++j) sh[(size_t)r * a.C + cc * 8 + j] = make_float2(s2[j >> 1][j & 1], q2[j >> 1][j & 1]);
     }
@@ -204,9 +303,12 @@ __global__ __launch_bounds__(NH_FIN_THREADS) void pgn_gn_nhwc_finalize_kernel(Nh
     const int ls = t / a.cpg, cl = t - ls * a.cpg;
     float s = 0.f, q = 0.f;
     if (ls < L) {
-        const float2* p = a.part + (size_t)n * a.S * a.C + (size_t)g * a.cpg + cl;
-        for (int sc = ls; sc < a.S; sc += L) {
-            const float2 v = p[(size_t)sc * a.C];
+        const int c = g * a.cpg + cl;
+        const bool second = a.part2 != nullptr && c >= a.partC;
+        const int pitch = second ? a.C - a.partC : a.partC, Sc = second ? a.part2S : a.partS;
+        const float2* p = second ? a.part2 + (size_t)n * Sc * pitch + (c - a.partC) : a.part + (size_t)n * Sc * pitch + c;
+        for (int sc = ls; sc < Sc; sc += L) {
+            const float2 v = p[(size_t)sc * pitch];
             s += v.x;
             q += v.y;
         }
@@ -1011,17 +1113,18 @@ static size_t nh_onepass_counter_bytes_fwd(int N) { return (((size_t)N * sizeof(
 #ifdef PGN_TUNING_HOOKS
 unsigned long long* g_nh_dbg = nullptr;
 int g_nh_reverse = 1;
+int g_brs_variant = 0;   // rows in flight / register budget of pgn_bias_res_stats_kernel (scripts/producer_stats_exp.py)
 int g_nh_target_wgs = 768, g_nh_min_rows_per_lane = 24;
 #else
 constexpr int g_nh_target_wgs = 768, g_nh_min_rows_per_lane = 24;
 constexpr int g_nh_reverse = 1;
 #endif
 
-// geometry shared by the workspace query and the launch
-static bool nh_geometry(int N, int C, int HW, int G, NhArgs* a) {
-    if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return false;
-    if ((C & 7) != 0 || C / 8 > NH_MAX_THREADS || C / G > 128) return false;
-    a->C = C; a->HW = HW; a->G = G; a->cpg = C / G; a->C8 = C / 8;
+// row-chunk geometry of the statistics / apply launches: a function of (N, C, HW) alone, so the launch that PRODUCES
+// a tensor can emit the partial statistics in it without knowing the consuming GroupNorm's group count
+static bool nh_chunking(int N, int C, int HW, NhArgs* a) {
+    if (N <= 0 || C <= 0 || HW <= 0 || (C & 7) != 0 || C / 8 > NH_MAX_THREADS) return false;
+    a->C = C; a->HW = HW; a->C8 = C / 8;
     int R = NH_MAX_THREADS / a->C8;
     if (R > HW) R = HW;
     if (R > 64) R = 64;
@@ -1034,6 +1137,15 @@ static bool nh_geometry(int N, int C, int HW, int G, NhArgs* a) {
     if (rows > HW) rows = HW;
     a->rows = (int)rows;
     a->S = (int)((HW + rows - 1) / rows);
+    return true;
+}
+
+// geometry shared by the workspace query and the launch
+static bool nh_geometry(int N, int C, int HW, int G, NhArgs* a) {
+    if (N <= 0 || C <= 0 || HW <= 0 || G <= 0 || (C % G) != 0) return false;
+    if ((C & 7) != 0 || C / 8 > NH_MAX_THREADS || C / G > 128) return false;
+    if (!nh_chunking(N, C, HW, a)) return false;
+    a->G = G; a->cpg = C / G;
     return true;
 }
 
@@ -1134,6 +1246,7 @@ static bool nh_ranges_overlap(const void* p, size_t pb, const void* q, size_t qb
 // measurement build only (make tuning): geometry sweep hook of scripts/gn_exp.py; absent from the shipped library
 extern "C" void pgn_groupnorm_nhwc_debug_buffer(void* p) { g_nh_dbg = (unsigned long long*)p; }
 extern "C" void pgn_groupnorm_nhwc_reverse(int on) { g_nh_reverse = on; }
+extern "C" void pgn_bias_res_stats_variant(int v) { g_brs_variant = v; }
 extern "C" void pgn_groupnorm_nhwc_tuning(int target_wgs, int min_rows_per_lane) {
     g_nh_target_wgs = target_wgs;
     g_nh_min_rows_per_lane = min_rows_per_lane;
@@ -1144,9 +1257,12 @@ extern "C" size_t pgn_groupnorm_nhwc_workspace_bytes(int N, int C, int HW, int G
     return nh_workspace_need(N, C, HW, G);
 }
 
+// pre1 / pre2: partial statistics the producers of x / x2 already wrote (pgn_bias_residual_add_stats), or nullptr: the
+// statistics launch runs here
 static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, const void* gamma, const void* beta,
                   int affine_dtype, const void* add_nc, int add_dtype, int N, int C, int HW, int G,
-                  float eps, int act, void* workspace, size_t workspace_bytes, void* stream) {
+                  float eps, int act, void* workspace, size_t workspace_bytes, void* stream,
+                  const void* pre1 = nullptr, const void* pre2 = nullptr) {
     if (x == nullptr || y == nullptr || workspace == nullptr) return PGN_ERR_INVALID;
     if (C1 <= 0 || C1 > C || (C1 < C) != (x2 != nullptr)) return PGN_ERR_INVALID;
     if ((C1 & 7) != 0) return PGN_ERR_UNSUPPORTED;
@@ -1172,8 +1288,15 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
     if ((gamma != nullptr && (!pgn_aligned(gamma, 16) || !pgn_aligned(beta, 16))) ||
         (add_nc != nullptr && !pgn_aligned(add_nc, 16)))
         return PGN_ERR_INVALID;
-    const size_t need = nh_workspace_need(N, C, HW, G);
+    const bool pre = pre1 != nullptr;
+    const size_t need = pre ? (size_t)N * G * sizeof(float2) : nh_workspace_need(N, C, HW, G);
     if (workspace_bytes < need) return PGN_ERR_INVALID;
+    NhArgs h1, h2;   // the producers' chunk geometry (pre only)
+    if (pre) {
+        if (add_nc != nullptr || (x2 != nullptr) != (pre2 != nullptr)) return PGN_ERR_INVALID;
+        if (!pgn_aligned(pre1, 8) || (pre2 != nullptr && !pgn_aligned(pre2, 8))) return PGN_ERR_INVALID;
+        if (!nh_chunking(N, C1, HW, &h1) || (x2 != nullptr && !nh_chunking(N, C - C1, HW, &h2))) return PGN_ERR_UNSUPPORTED;
+    }
     a.x = x; a.x2 = x2; a.C1 = C1; a.y = y; a.gamma = gamma; a.beta = beta; a.addnc = add_nc; a.adt = affine_dtype; a.add_dt = add_dtype;
     a.eps = eps; a.act = act;
     // Three-pass form: the apply pass re-reads what the statistics pass read.  Tensors of up to ~170 MB are still in
@@ -1184,11 +1307,32 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
     // (smaller launches, and the range's own output evicts the rows it has not re-read yet).
     a.reverse = (g_nh_reverse && (size_t)N * HW * C * pgn_dtype_size(dtype) > ((size_t)200 << 20)) ? 1 : 0;
     a.arrived = nullptr; a.gpart = nullptr; a.timeout = 0;
+    a.part = nullptr; a.stats = nullptr; a.part2 = nullptr; a.partS = 0; a.partC = 0; a.part2S = 0;
 #ifdef PGN_TUNING_HOOKS
     a.dbg = g_nh_dbg;
 #endif
     hipStream_t s = (hipStream_t)stream;
     const bool has_add = add_nc != nullptr;
+    if (pre) {
+        // the producers' partials stand in for the statistics launch: finalize + apply, one read + one write
+        a.part = nullptr; a.partS = h1.S; a.partC = C1; a.part2 = (const float2*)pre2; a.part2S = x2 != nullptr ? h2.S : 0;
+        a.stats = (float2*)workspace;
+        NhArgs f = a;
+        f.part = (float2*)const_cast<void*>(pre1);
+        const int threads = ((a.R * a.C8 + 63) / 64) * 64;
+        const dim3 grid((unsigned)(N * a.S)), block(threads);
+#define PGN_NH_PRE(DT)                                                                                               \
+    do {                                                                                                             \
+        hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<DT>), dim3(N * G), dim3(NH_FIN_THREADS), 0, s, f);           \
+        if (act) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, false, true>), grid, block, 0, s, f);              \
+        else hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, false, false>), grid, block, 0, s, f);                 \
+    } while (0)
+        if (dtype == PGN_BF16) PGN_NH_PRE(PGN_BF16);
+        else PGN_NH_PRE(PGN_F16);
+#undef PGN_NH_PRE
+        PGN_LAUNCH_CHECK();
+        return PGN_OK;
+    }
 #ifdef PGN_TUNING_HOOKS
     {
         // Pipelined one-pass form (1R + 1W, persistent workgroups): measurement build only, and only on request
@@ -1279,6 +1423,7 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
         }
     }
     a.part = (float2*)workspace;
+    a.partS = a.S; a.partC = C; a.part2 = nullptr; a.part2S = 0;
     a.stats = a.part + (size_t)N * a.S * C;
     const int threads = ((a.R * a.C8 + 63) / 64) * 64;
     const size_t lds = (size_t)a.R * C * sizeof(float2);
@@ -1315,6 +1460,77 @@ extern "C" int pgn_groupnorm_silu_nhwc_cat(const void* x1, int C1, const void* x
     if ((C2 & 7) != 0) return PGN_ERR_UNSUPPORTED;
     return nh_run(x1, C1, x2, y, dtype, gamma, beta, affine_dtype, add_nc, add_dtype, N, C1 + C2, HW, G, eps, act,
                   workspace, workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Producer-side statistics (include/pigeon_hip.h: pgn_bias_residual_add_stats, pgn_groupnorm_silu_nhwc_pre)
+extern "C" size_t pgn_bias_residual_add_stats_bytes(int N, int C, int HW) {
+    NhArgs a;
+    if (!nh_chunking(N, C, HW, &a) || (long long)N * a.S > 0x7fffffffLL) return 0;
+    return (size_t)N * a.S * C * sizeof(float2);
+}
+
+extern "C" int pgn_bias_residual_add_stats(const void* x, const void* residual, const void* bias, int bias_dtype,
+                                           void* y, int dtype, int N, int C, int HW, void* part, size_t part_bytes,
+                                           void* stream) {
+    if (x == nullptr || bias == nullptr || y == nullptr || part == nullptr) return PGN_ERR_INVALID;
+    if (N <= 0 || C <= 0 || HW <= 0 || pgn_dtype_size(bias_dtype) == 0) return PGN_ERR_INVALID;
+    if (dtype != PGN_BF16 && dtype != PGN_F16) return PGN_ERR_UNSUPPORTED;
+    NhArgs a;
+    if (!nh_chunking(N, C, HW, &a)) return PGN_ERR_UNSUPPORTED;
+    if ((long long)N * a.S > 0x7fffffffLL || (long long)N * HW * C > 0x7fffffffffffLL) return PGN_ERR_UNSUPPORTED;
+    if (!pgn_aligned(x, 16) || !pgn_aligned(y, 16) || !pgn_aligned(bias, 16) || !pgn_aligned(part, 8) ||
+        (residual != nullptr && !pgn_aligned(residual, 16)))
+        return PGN_ERR_INVALID;
+    if (part_bytes < (size_t)N * a.S * C * sizeof(float2)) return PGN_ERR_INVALID;
+    // every workgroup of a sample reads the pivot rows of the INPUTS: y may alias neither
+    const size_t tb = (size_t)N * HW * C * pgn_dtype_size(dtype);
+    if (nh_ranges_overlap(x, tb, y, tb) || (residual != nullptr && nh_ranges_overlap(residual, tb, y, tb)))
+        return PGN_ERR_INVALID;
+    a.x = x; a.x2 = nullptr; a.C1 = C; a.y = y; a.gamma = nullptr; a.beta = nullptr; a.addnc = nullptr;
+    a.adt = PGN_F32; a.add_dt = PGN_F32; a.G = 0; a.cpg = 0; a.eps = 0.f; a.act = 0; a.reverse = 0;
+    a.part = (float2*)part; a.stats = nullptr; a.part2 = nullptr; a.partS = a.S; a.partC = C; a.part2S = 0;
+    a.arrived = nullptr; a.gpart = nullptr; a.timeout = 0;
+#ifdef PGN_TUNING_HOOKS
+    a.dbg = nullptr;
+#endif
+    hipStream_t s = (hipStream_t)stream;
+    const int threads = ((a.R * a.C8 + 63) / 64) * 64;
+    const size_t lds = (size_t)a.R * C * sizeof(float2);
+    const dim3 grid((unsigned)(N * a.S)), block(threads);
+#define PGN_BRS_V(DT, U, W)                                                                                          \
+    do {                                                                                                             \
+        if (residual) hipLaunchKernelGGL((pgn_bias_res_stats_kernel<DT, true, U, W>), grid, block, lds, s, a, residual, bias, bias_dtype);  \
+        else hipLaunchKernelGGL((pgn_bias_res_stats_kernel<DT, false, U, W>), grid, block, lds, s, a, residual, bias, bias_dtype);          \
+    } while (0)
+#ifdef PGN_TUNING_HOOKS
+#define PGN_BRS(DT)                                                                                                  \
+    do {                                                                                                             \
+        if (g_brs_variant == 1) PGN_BRS_V(DT, 4, 4);                                                                 \
+        else if (g_brs_variant == 2) PGN_BRS_V(DT, 2, 8);                                                            \
+        else if (g_brs_variant == 3) PGN_BRS_V(DT, 1, 8);                                                            \
+        else PGN_BRS_V(DT, 2, 4);                                                                                    \
+    } while (0)
+#else
+#define PGN_BRS(DT) PGN_BRS_V(DT, 2, 4)
+#endif
+    if (dtype == PGN_BF16) PGN_BRS(PGN_BF16);
+    else PGN_BRS(PGN_F16);
+#undef PGN_BRS
+#undef PGN_BRS_V
+    PGN_LAUNCH_CHECK();
+    return PGN_OK;
+}
+
+extern "C" int pgn_groupnorm_silu_nhwc_pre(const void* x1, int C1, const void* part1, const void* x2, int C2,
+                                           const void* part2, void* y, int dtype, const void* gamma, const void* beta,
+                                           int affine_dtype, int N, int HW, int G, float eps, int act, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    if (part1 == nullptr || C1 <= 0 || C2 < 0 || (C2 > 0) != (x2 != nullptr)) return PGN_ERR_INVALID;
+    if ((C2 & 7) != 0) return PGN_ERR_UNSUPPORTED;
+    if (act != 0 && act != PGN_GN_ACT_SILU) return PGN_ERR_INVALID;
+    return nh_run(x1, C1, x2, y, dtype, gamma, beta, affine_dtype, nullptr, PGN_F32, N, C1 + C2, HW, G, eps, act,
+                  workspace, workspace_bytes, stream, part1, part2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -68,6 +68,12 @@ def _bias_fusable(conv: nn.Conv2d, x: torch.Tensor) -> bool:
             and conv.out_channels % 8 == 0)
 
 
+# PGN_PRODUCER_STATS=0: every GroupNorm computes its own statistics (A/B switch).  Default: the launch that adds a
+# convolution's bias / a block's residual also emits the partial statistics of the GroupNorm that reads its output
+# (ops.bias_residual_add(..., gn_stats=True)): that GroupNorm then reads the tensor once instead of twice.
+PRODUCER_STATS = os.environ.get("PGN_PRODUCER_STATS", "1") != "0"
+
+
 def conv2d_bias(conv: nn.Conv2d, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """conv(x) [+ residual] with the bias (and the residual) added by ops.bias_residual_add in one launch."""
     if not _bias_fusable(conv, x):
@@ -77,7 +83,7 @@ def conv2d_bias(conv: nn.Conv2d, x: torch.Tensor, residual: Optional[torch.Tenso
     if not (y.is_contiguous(memory_format=torch.channels_last) or (y.is_contiguous() and (y.shape[2] * y.shape[3]) % 8 == 0)):
         y = y + conv.bias.view(1, -1, 1, 1)
         return y if residual is None else y + residual
-    return ops.bias_residual_add(y, conv.bias, residual)
+    return ops.bias_residual_add(y, conv.bias, residual, gn_stats=PRODUCER_STATS)
 
 
 # PGN_SPLIT_CONCAT=0: the up blocks write torch.cat([hidden, skip]) and the 1x1 shortcuts stay MIOpen convolutions
@@ -192,7 +198,7 @@ class ResnetBlock2D(nn.Module):
             if skip is not None:
                 rows.addmm_(_nhwc_rows(skip), w[:, c1:].t())
             b = self._shortcut_bias(hh.dtype)
-            out = ops.bias_residual_add(hh, b, None)
+            out = ops.bias_residual_add(hh, b, None, gn_stats=PRODUCER_STATS)
         elif _bias_fusable(self.conv2, h):
             # both biases in one vector: shortcut(x) + b_s + conv2(h) + b_2
             sc = _conv_nobias(self.conv_shortcut, input_tensor)
@@ -200,7 +206,7 @@ class ResnetBlock2D(nn.Module):
             if hh.stride() == sc.stride() and (hh.is_contiguous(memory_format=torch.channels_last)
                                                or (hh.is_contiguous() and (hh.shape[2] * hh.shape[3]) % 8 == 0)):
                 b = self._shortcut_bias(hh.dtype)
-                out = ops.bias_residual_add(hh, b, sc)
+                out = ops.bias_residual_add(hh, b, sc, gn_stats=PRODUCER_STATS)
             else:
                 out = (sc + self.conv_shortcut.bias.view(1, -1, 1, 1)) + (hh + self.conv2.bias.view(1, -1, 1, 1))
         else:

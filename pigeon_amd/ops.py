@@ -364,12 +364,49 @@ def _gn_nhwc_act(silu: bool) -> int:
     return act
 
 
+# Producer-side GroupNorm statistics are emitted for activations ABOVE this size: up to 32 MiB the consuming GroupNorm
+# runs as ONE launch (one-pass form, 1 read + 1 write already) and partials would only add a finalize launch.
+GN_STATS_MIN_BYTES = 32 << 20
+
+
+def _gn_stats_bytes(N: int, C: int, HW: int, elem: int) -> int:
+    if N * C * HW * elem <= GN_STATS_MIN_BYTES:
+        return 0
+    return int(_lib.load().pgn_bias_residual_add_stats_bytes(N, C, HW))
+
+
+def gn_stats_applicable(x: torch.Tensor) -> bool:
+    """Would bias_residual_add(x, ..., gn_stats=True) emit partial statistics for this activation?"""
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and _is_channels_last(x) and not x.is_contiguous()):
+        return False
+    N, C, H, W = x.shape
+    return _gn_stats_bytes(N, C, H * W, x.element_size()) > 0
+
+
+def gn_partials(t: Optional[torch.Tensor]):
+    """The partial GroupNorm statistics that rode along with `t` from the launch that produced it
+    (bias_residual_add(..., gn_stats=True)), or None: none were emitted, or `t` has been written since."""
+    hit = getattr(t, "_pgn_gn_part", None) if t is not None else None
+    if hit is None or hit[0] != t._version or hit[1] != t.data_ptr():
+        return None
+    return hit[2]
+
+
 def _group_norm_silu_nhwc(x, num_groups, weight, bias, eps, silu, add_nc, x2=None):
-    """channels_last input -> channels_last output through pgn_groupnorm_silu_nhwc (no layout change, no copy)."""
+    """channels_last input -> channels_last output through pgn_groupnorm_silu_nhwc (no layout change, no copy).
+    Inputs that bring their producer's partial statistics (gn_partials) skip the statistics launch
+    (pgn_groupnorm_silu_nhwc_pre: one read + one write of the tensor instead of two + one)."""
     lib = _lib.load()
     N, C1, H, W = x.shape
     C = C1 + (x2.shape[1] if x2 is not None else 0)
     HW = H * W
+    pre = None
+    if add_nc is None:
+        p1, p2 = gn_partials(x), gn_partials(x2)
+        if p1 is not None and (x2 is None or p2 is not None):
+            if (p1.numel() == int(lib.pgn_bias_residual_add_stats_bytes(N, C1, HW)) and
+                    (x2 is None or p2.numel() == int(lib.pgn_bias_residual_add_stats_bytes(N, C - C1, HW)))):
+                pre = (p1, p2)
     if (weight is None) != (bias is None):
         raise ValueError("weight and bias must both be given or both be None")
     adt = PGN_F32
@@ -388,12 +425,16 @@ def _group_norm_silu_nhwc(x, num_groups, weight, bias, eps, silu, add_nc, x2=Non
         y = torch.empty_like(x)     # preserves the channels_last strides
     else:
         y = torch.empty((N, C, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    ws_bytes = int(lib.pgn_groupnorm_nhwc_workspace_bytes(N, C, HW, int(num_groups)))
+    ws_bytes = 8 * N * int(num_groups) if pre else int(lib.pgn_groupnorm_nhwc_workspace_bytes(N, C, HW, int(num_groups)))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=x.device)
     act = _gn_nhwc_act(silu)
 
     def run():
-        if x2 is None:
+        if pre is not None:
+            rc = lib.pgn_groupnorm_silu_nhwc_pre(_ptr(x), C1, _ptr(pre[0]), _ptr(x2), C - C1, _ptr(pre[1]), _ptr(y),
+                                                 _dt(x), _ptr(weight), _ptr(bias), adt, N, HW, int(num_groups),
+                                                 float(eps), 1 if silu else 0, _ptr(ws), ws_bytes, _stream())
+        elif x2 is None:
             rc = lib.pgn_groupnorm_silu_nhwc(_ptr(x), _ptr(y), _dt(x), _ptr(weight), _ptr(bias), adt, _ptr(add_nc),
                                              add_dt, N, C, HW, int(num_groups), float(eps), act, _ptr(ws),
                                              ws_bytes, _stream())
@@ -450,9 +491,14 @@ def geglu(h: torch.Tensor) -> torch.Tensor:
 
 
 def bias_residual_add(x: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None,
-                      inplace: bool = True) -> torch.Tensor:
+                      inplace: bool = True, gn_stats: bool = False) -> torch.Tensor:
     """x + bias[c] (+ residual) for a [N, C, H, W] activation in NCHW or channels_last memory, one launch.
-    `x` is overwritten unless inplace=False (it is the fresh output of a bias-less convolution)."""
+    `x` is overwritten unless inplace=False (it is the fresh output of a bias-less convolution).
+
+    gn_stats: the result feeds a channels-last GroupNorm.  Where the library's form applies (channels_last, tensor above
+    32 MiB: pgn_bias_residual_add_stats) the same launch emits that GroupNorm's partial statistics; they ride on the
+    returned tensor (a NEW tensor then: the launch does not work in place) and group_norm_silu / group_norm_silu_cat
+    pick them up as long as the tensor has not been written since (gn_partials).  Values are bit-identical either way."""
     lib = _lib.load()
     _dev(x, bias, residual)
     if x.dim() != 4:
@@ -472,14 +518,31 @@ def bias_residual_add(x: torch.Tensor, bias: torch.Tensor, residual: Optional[to
     if bias.numel() != C:
         raise ValueError("bias must be [C]")
     bias = bias.contiguous()
+    work = float(x.numel() * x.element_size() * (3 if residual is not None else 2))
+    if gn_stats and inner == 1 and x.dtype in (torch.bfloat16, torch.float16) and bias.data_ptr() % 16 == 0:
+        part_bytes = _gn_stats_bytes(N, C, H * W, x.element_size())
+        if part_bytes:
+            y = torch.empty_like(x)
+            part = torch.empty(part_bytes, dtype=torch.uint8, device=x.device)
+
+            def run_stats():
+                rc = lib.pgn_bias_residual_add_stats(_ptr(x), _ptr(residual), _ptr(bias), _dt(bias), _ptr(y), _dt(x), N, C,
+                                                     H * W, _ptr(part), part_bytes, _stream())
+                _lib.check(rc, "pgn_bias_residual_add_stats")
+
+            _launch("bias_residual", work, run_stats)
+            y._pgn_gn_part = (y._version, y.data_ptr(), part)
+            return y
     y = x if inplace else torch.empty_like(x)
+    if inplace and getattr(x, "_pgn_gn_part", None) is not None:
+        del x._pgn_gn_part          # written through a raw pointer: torch's version counter does not see it
 
     def run():
         rc = lib.pgn_bias_residual_add(_ptr(x), _ptr(residual), _ptr(bias), _dt(bias), _ptr(y), _dt(x), rows, C, inner,
                                        _stream())
         _lib.check(rc, "pgn_bias_residual_add")
 
-    _launch("bias_residual", float(x.numel() * x.element_size() * (3 if residual is not None else 2)), run)
+    _launch("bias_residual", work, run)
     return y
 
 

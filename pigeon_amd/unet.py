@@ -19,7 +19,7 @@ from typing import Any, Dict, Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import layers, ops
 from .attention_processor import Attention, HipAttnProcessor
 from .layers import (Downsample2D, GroupNormAct, ResnetBlock2D, TimestepEmbedding, Upsample2D, conv2d_bias,
                      derived_constant,
@@ -200,16 +200,23 @@ class Transformer2DModel(nn.Module):
         # NCHW activations need the transposing copy diffusers makes
         cl = residual.is_contiguous(memory_format=torch.channels_last) and not residual.is_contiguous()
         if self.use_linear_projection:
-            if cb is None:
-                hidden_states = self.proj_out(hidden_states)
-            else:
+            po = self.proj_out
+            dt = hidden_states.dtype
+            b_eff = po.bias
+            if cb is not None:
                 # the last block's pending bias goes through the projection as a bias term: W (x + cb) + b
-                po = self.proj_out
-                dt = hidden_states.dtype
                 b_eff = derived_constant(
                     self, f"_pgn_b_eff_{dt}", (po.weight, po.bias, cb),
                     lambda: (po.weight.detach().float() @ cb + (0.0 if po.bias is None else po.bias.detach().float())).to(dt))
-                hidden_states = torch.nn.functional.linear(hidden_states, po.weight, b_eff)
+            if (layers.PRODUCER_STATS and cl and b_eff is not None and b_eff.dtype == dt and po.weight.dtype == dt
+                    and ops.gn_stats_applicable(residual)):
+                # the module's output feeds the next ResnetBlock2D's norm1 (alone or as one half of an up block's
+                # concatenation): bias and residual are added by the launch that also emits that GroupNorm's
+                # partial statistics, instead of a GEMM bias epilogue + a torch add (the same three tensor passes)
+                hidden_states = torch.nn.functional.linear(hidden_states, po.weight)
+                hidden_states = hidden_states.reshape(b, h, w, c).permute(0, 3, 1, 2)
+                return ops.bias_residual_add(hidden_states, b_eff, residual, inplace=False, gn_stats=True)
+            hidden_states = torch.nn.functional.linear(hidden_states, po.weight, b_eff)
             hidden_states = hidden_states.reshape(b, h, w, c).permute(0, 3, 1, 2)
             if not cl:
                 hidden_states = hidden_states.contiguous()

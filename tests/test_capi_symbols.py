@@ -67,7 +67,7 @@ def test_binding_table_matches_header():
 
 def test_version_and_error_strings_need_no_gpu():
     lib = _lib.load()
-    assert lib.pgn_version() == 111
+    assert lib.pgn_version() == 112
     assert lib.pgn_error_string(0) == b"ok"
     assert b"invalid" in lib.pgn_error_string(-1)
     assert lib.pgn_workspace_bytes(3) == 0

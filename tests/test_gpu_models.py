@@ -66,7 +66,7 @@ def stack():
 
 def test_native_library_is_the_one_in_tree(stack):
     from pigeon_amd import _lib
-    assert _lib.load().pgn_version() == 111
+    assert _lib.load().pgn_version() == 112
     maps = open("/proc/self/maps").read()
     assert "pigeon_amd/lib/libpigeon_hip.so" in maps
 
@@ -490,7 +490,8 @@ def test_fused_qkv_projection_equals_separate_projections(stack, monkeypatch):
 
 @pytest.mark.parametrize("switch", [("pigeon_amd.unet", "ACCUMULATE_ATTENTION"), ("pigeon_amd.unet", "ACCUMULATE_FF"),
                                     ("pigeon_amd.layers", "FUSE_CONV_BIAS"), ("pigeon_amd.layers", "SPLIT_CONCAT"),
-                                    ("pigeon_amd.layers", "HIP_UPSAMPLE"), ("pigeon_amd.layers", "KEEP_DERIVED")])
+                                    ("pigeon_amd.layers", "HIP_UPSAMPLE"), ("pigeon_amd.layers", "KEEP_DERIVED"),
+                                    ("pigeon_amd.layers", "PRODUCER_STATS")])
 def test_host_side_restructurings_agree_with_the_plain_order(stack, monkeypatch, switch):
     # every restructuring around the library GEMMs / convolutions (INTEGRATION.md switch table) is the same real
     # arithmetic in another order: switched off, the UNet and the VAE agree with the default build to the bf16 floor
