@@ -58,6 +58,16 @@ for with_res in (True, False):
                 return fused_add()
             cases[f"fused add v{v}"] = f_add
             cases[f"fused pair v{v}"] = lambda v=v: ops.group_norm_silu(cases[f"fused add v{v}"](), 32, g, b, 1e-5, True)
+        lib.pgn_groupnorm_nhwc_reverse.argtypes = [ctypes.c_int]
+        lib.pgn_groupnorm_nhwc_reverse.restype = None
+
+        def pair_forward_walk():
+            lib.pgn_bias_res_stats_variant(0)
+            lib.pgn_groupnorm_nhwc_reverse(0)      # apply pass walks the tensor forwards (default: backwards above 200 MB)
+            y = ops.group_norm_silu(fused_add(), 32, g, b, 1e-5, True)
+            lib.pgn_groupnorm_nhwc_reverse(1)
+            return y
+        cases["fused pair v0, forward apply walk"] = pair_forward_walk
         best = {k: 1e9 for k in cases}
         for rnd in range(3):
             for k, fn in cases.items():
