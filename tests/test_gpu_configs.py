@@ -126,6 +126,49 @@ def test_config4_multi_candidate_ordering(sdxl):
     assert _rel(d2[1], d2[0]) < 0.05 and _rel(d2[2], d2[0]) > 0.5
 
 
+def test_config2_share_at_full_size_batch_8_1216x832(sdxl):
+    # BASELINE configs[2] as bench.py --config 2 runs it: the one-GPU share of 8 images at 1216x832 on the 50-step
+    # schedule (UNet batch 16, N = 3952 / 988), three steps; rows 2..3 run alone must reproduce rows 2..3 of the batch
+    toks = _tokens(8, 31)
+    noise = torch.randn(8, 4, 152, 104, generator=torch.Generator().manual_seed(77)).to(DEV)
+    kw = dict(width=832, height=1216, num_inference_steps=50, guidance_scale_for_diffusion=7.0, output_type="latent")
+
+    class Stop(Exception):
+        pass
+
+    def run(tk, nz):
+        seen = []
+
+        def cb(i, t, x):
+            seen.append(x.clone())
+            if i == 2:
+                raise Stop
+        with pytest.raises(Stop):
+            sdxl.generate_image(image_tokens=tk, latents=nz, callback=cb, **kw)
+        return seen[-1]
+
+    full = run(toks, noise)
+    assert full.shape == (8, 4, 152, 104) and torch.isfinite(full).all()
+    part = run(toks[2:4], noise[2:4])
+    assert _rel(part, full[2:4]) < 0.06 and _rel(part, full[4:6]) > 0.5
+
+
+def test_config3_share_at_full_size_two_sequences_times_eight(sdxl):
+    # BASELINE configs[3] as bench.py --config 3 runs it: 2 token sequences x 8 candidates at 1024x1024 (UNet batch 32,
+    # the bench's kernel shapes), two steps, decoded: candidate rows of sequence 1 run alone reproduce rows 8..15, and
+    # the images come back as 16 uint8 pictures
+    toks = _tokens(2, 41)
+    noise = torch.randn(16, 4, 128, 128, generator=torch.Generator().manual_seed(19)).to(DEV)
+    kw = dict(width=1024, height=1024, num_inference_steps=2, guidance_scale_for_diffusion=7.0)
+    both = sdxl.generate_image(image_tokens=toks, num_return_images=8, latents=noise, output_type="latent", **kw)[0]
+    assert both.shape == (16, 4, 128, 128) and torch.isfinite(both).all()
+    second = sdxl.generate_image(image_tokens=toks[1:], num_return_images=8, latents=noise[8:], output_type="latent", **kw)[0]
+    assert _rel(second, both[8:]) < 0.05 and _rel(second, both[:8]) > 0.5
+    images = sdxl.decode_latents(both[:2], "uint8")
+    assert images.shape == (2, 1024, 1024, 3) and images.dtype == torch.uint8
+    assert 5 < images.float().mean().item() < 250
+
+
 def test_config5_high_resolution_attention_shapes():
     # 2x latent side: self-attention over N = 16384 (level 1) / 4096 (level 2); cross-attention key length swept to 1024
     from oracle import ops_ref
