@@ -508,9 +508,15 @@ def test_host_side_restructurings_agree_with_the_plain_order(stack, monkeypatch,
     assert _rel(a, b)[1] < 0.02 and _rel(va, vb)[1] < 0.02
 
 
-def test_hip_graph_replay_equals_eager_loop(stack):
+@pytest.mark.parametrize("producer_stats", [False, True], ids=["default", "producer_stats"])
+def test_hip_graph_replay_equals_eager_loop(stack, monkeypatch, producer_stats):
     # enable_hip_graph(): the whole denoising loop is captured once per (shape, schedule, guidance) and replayed;
-    # same kernels, same order -> same latents as the eager loop up to the GEMMs' run-to-run noise floor
+    # same kernels, same order -> same latents as the eager loop up to the GEMMs' run-to-run noise floor.
+    # producer_stats: the GroupNorm partial statistics that ride on tensors between launches (ops.gn_partials; by
+    # default only above 32 MiB, i.e. never at this size) are allocated and consumed under capture as well
+    if producer_stats:
+        from pigeon_amd import ops as _ops
+        monkeypatch.setattr(_ops, "GN_STATS_MIN_BYTES", 0)
     pipe = stack["pipe"]
     kw = dict(width=128, height=160, num_inference_steps=3, guidance_scale_for_diffusion=7.0, output_type="latent")
     toks_a, toks_b = weights.synth_tokens(2, seed=11), weights.synth_tokens(2, seed=12)
