@@ -130,19 +130,30 @@ class HipAttnProcessor:
                 and getattr(attn, "group_norm", None) is None and not getattr(attn, "norm_cross", None)
                 and not attn.residual_connection and attn.rescale_output_factor == 1.0)
 
+    def skipped_rows(self, attn: "Attention", batch: int, encoder_hidden_states: Optional[torch.Tensor],
+                     attention_mask: Optional[torch.Tensor]) -> int:
+        """How many leading batch rows `accumulate` leaves out of a cross-attention call (the all-zero-context rows of
+        the CFG pair): the caller need not compute the LayerNorm that only feeds this call's query for them."""
+        k0 = self.zero_ctx_rows
+        if (encoder_hidden_states is not None and 0 < k0 < batch and attention_mask is None and attn.to_k.bias is None
+                and attn.to_v.bias is None):
+            return k0
+        return 0
+
     def accumulate(self, attn: "Attention", hidden_states: torch.Tensor, residual: torch.Tensor,
                    encoder_hidden_states: Optional[torch.Tensor] = None,
-                   attention_mask: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                   attention_mask: Optional[torch.Tensor] = None, hidden_row0: int = 0) -> Optional[torch.Tensor]:
         """residual += attention(hidden_states) @ to_out.weight^T IN PLACE (a GEMM with beta = 1: no separate add
         launch) and return to_out's bias, which the caller carries as a pending per-channel vector into the next
-        LayerNorm (ops.add_layer_norm col_bias).  Rows of an all-zero context (zero_ctx_rows) receive nothing."""
-        B, N, C = hidden_states.shape
+        LayerNorm (ops.add_layer_norm col_bias).  Rows of an all-zero context (zero_ctx_rows) receive nothing.
+        hidden_row0: `hidden_states` starts at that batch row of `residual` (0, or skipped_rows() when the caller
+        normalised only the rows this call reads)."""
+        B, N, C = residual.shape
         is_cross = encoder_hidden_states is not None
-        k0 = self.zero_ctx_rows
-        if not (is_cross and 0 < k0 < B and attention_mask is None and attn.to_k.bias is None
-                and attn.to_v.bias is None):
-            k0 = 0
-        hs = hidden_states[k0:]
+        k0 = self.skipped_rows(attn, B, encoder_hidden_states, attention_mask)
+        if hidden_row0 not in (0, k0) or hidden_states.shape[0] != B - hidden_row0:
+            raise ValueError("accumulate: hidden_states must cover the batch rows from 0 or from skipped_rows()")
+        hs = hidden_states if hidden_row0 == k0 else hidden_states[k0:]
         if not is_cross:
             query, key, value = self._self_qkv(attn, hs)
         else:

@@ -62,6 +62,9 @@ SD15_CONFIG = dict(
 # A/B switch for measurements: PGN_ACCUMULATE_ATTENTION=0 restores add + LayerNorm after every attention layer
 ACCUMULATE_ATTENTION = os.environ.get("PGN_ACCUMULATE_ATTENTION", "1") != "0"
 ACCUMULATE_FF = os.environ.get("PGN_ACCUMULATE_FF", "1") != "0"
+# PGN_SKIP_UNUSED_NORM2=0: norm2 of a transformer block is computed for every batch row, also for the rows whose
+# cross-attention is skipped (all-zero context: the unconditional half of the CFG pair)
+SKIP_UNUSED_NORM2 = os.environ.get("PGN_SKIP_UNUSED_NORM2", "1") != "0"
 
 
 class GEGLU(nn.Module):
@@ -138,8 +141,13 @@ class BasicTransformerBlock(nn.Module):
                 cb_in = None                              # materialised into the fresh sum by norm1
             c1, c12, c123 = self._pending_biases(cb_in)
             p1.accumulate(self.attn1, h, hidden_states, None, attention_mask)
-            _, h = ops.add_layer_norm(hidden_states, None, n2.weight, n2.bias, n2.eps, col_bias=c1)
-            p2.accumulate(self.attn2, h, hidden_states, encoder_hidden_states, encoder_attention_mask)
+            # norm2 feeds attn2's query only, and attn2 leaves out the all-zero-context rows of the CFG pair: their
+            # LayerNorm is not computed either (SKIP_UNUSED_NORM2)
+            k0 = p2.skipped_rows(self.attn2, hidden_states.shape[0], encoder_hidden_states, encoder_attention_mask) \
+                if SKIP_UNUSED_NORM2 else 0
+            _, h = ops.add_layer_norm(hidden_states[k0:] if k0 else hidden_states, None, n2.weight, n2.bias, n2.eps,
+                                      col_bias=c1)
+            p2.accumulate(self.attn2, h, hidden_states, encoder_hidden_states, encoder_attention_mask, hidden_row0=k0)
             _, h = ops.add_layer_norm(hidden_states, None, n3.weight, n3.bias, n3.eps, col_bias=c12)
             lin2 = self.ff.net[2]
             if ACCUMULATE_FF and defer_add and isinstance(lin2, nn.Linear):

@@ -31,6 +31,7 @@ SCHED = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", 
 
 # every restructuring switch of the host side (INTEGRATION.md switch table), all off at once = the plain module graph
 ALL_SWITCHES = [("pigeon_amd.unet", "ACCUMULATE_ATTENTION"), ("pigeon_amd.unet", "ACCUMULATE_FF"),
+                ("pigeon_amd.unet", "SKIP_UNUSED_NORM2"),
                 ("pigeon_amd.attention_processor", "_FUSE_QKV"), ("pigeon_amd.layers", "FUSE_CONV_BIAS"),
                 ("pigeon_amd.layers", "SPLIT_CONCAT"), ("pigeon_amd.layers", "KEEP_DERIVED"),
                 ("pigeon_amd.layers", "HIP_UPSAMPLE"), ("pigeon_amd.layers", "PRODUCER_STATS")]

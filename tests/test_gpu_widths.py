@@ -103,7 +103,30 @@ def test_basic_transformer_block_fp16_and_zero_context_rows():
     for p in (blk.attn1.processor, blk.attn2.processor):
         assert isinstance(p, HipAttnProcessor)
         p.zero_ctx_rows = 1
-    _check(blk(x.to(DEV), ctx.to(DEV)), want0, BLOCK_BAR[dt], "BasicTransformerBlock fp16, zero-context row skipped")
+    got_skip = blk(x.to(DEV), ctx.to(DEV))
+    _check(got_skip, want0, BLOCK_BAR[dt], "BasicTransformerBlock fp16, zero-context row skipped")
+    # norm2 of the skipped row is not computed either (unet.SKIP_UNUSED_NORM2): the LayerNorm launch in front of attn2
+    # sees one row of the pair, and nothing changes in the result
+    from pigeon_amd import ops, unet as unet_mod
+    seen = []
+    real = ops.add_layer_norm
+
+    def spy(xx, *a, **k):
+        seen.append(xx.shape[0])
+        return real(xx, *a, **k)
+    ops.add_layer_norm = spy
+    try:
+        again = blk(x.to(DEV), ctx.to(DEV))
+        assert seen == [2, 1, 2], seen
+        seen.clear()
+        unet_mod.SKIP_UNUSED_NORM2 = False
+        full_norm = blk(x.to(DEV), ctx.to(DEV))
+        assert seen == [2, 2, 2], seen
+    finally:
+        ops.add_layer_norm = real
+        unet_mod.SKIP_UNUSED_NORM2 = True
+    # same launches on the same rows either way (a LayerNorm row does not depend on its neighbours)
+    assert _rel(again, got_skip) < 1e-4 and _rel(full_norm, got_skip) < 1e-4
 
 
 # ---- Transformer2DModel, 10 blocks: the pending-bias chain and proj_out's effective bias -------------------------
