@@ -410,6 +410,9 @@ def main():
                        "tuned_gemms": bool(pipe.tuned_gemms), "miopen_db_hit": bool(pipe.miopen_db_hit)},
             # ranks that joined the RCCL (backend "nccl") process group; 0 for a one-rank run or a gloo rehearsal
             "rccl_ranks": world if (world > 1 and args.dist_backend == "nccl") else 0,
+            # peak of torch's allocator on this rank over build + warm-up + timed steps (weights, activations, library
+            # workspaces it serves); of 288 GB per MI355X
+            "hbm_peak_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
             # embeds + denoising loop only (no VAE decode / uint8 copy), this rank's GPU time per step
             "loop_only": {"images_per_sec_per_gpu": args.batch / (loop_ms * 1e-3) if loop_ms > 0 else None,
                           "ms_per_step": loop_ms if loop_ms > 0 else None},
