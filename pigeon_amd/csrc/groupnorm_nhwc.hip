@@ -343,8 +343,9 @@ __global__ __launch_bounds__(NH_FIN_THREADS) void pgn_gn_nhwc_finalize_kernel(Nh
     if (t == 0) a.stats[(size_t)n * a.G + g] = make_float2(mean, 1.0f / sqrtf(var + a.eps));
 }
 
-template <int DT, bool HAS_ADD, bool ACT>
-__global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArgs a) {
+// U rows in flight per lane, WPS waves per SIMD the register budget is cut for (swept: scripts/gn_apply_sweep.py)
+template <int DT, bool HAS_ADD, bool ACT, int U = 4, int WPS = 4>
+__global__ __launch_bounds__(NH_MAX_THREADS, WPS) void pgn_gn_nhwc_apply_kernel(NhArgs a) {
     const unsigned bid = a.reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int n = bid / a.S, sc = bid % a.S;
     const int t = threadIdx.x;
@@ -387,14 +388,26 @@ __global__ __launch_bounds__(NH_MAX_THREADS) void pgn_gn_nhwc_apply_kernel(NhArg
         *reinterpret_cast<u16x8_t*>(yp + e) = o;
     };
     int row = sc * a.rows + r;
-    for (; row + 3 * a.R < row1; row += 4 * a.R) {
-        const size_t e0 = img + (size_t)row * a.C + cc * 8, st = (size_t)a.R * a.C;
-        const size_t i0 = (size_t)row * pitch, si = (size_t)a.R * pitch;
-        const u16x8_t v0 = *reinterpret_cast<const u16x8_t*>(xp + i0);
-        const u16x8_t v1 = *reinterpret_cast<const u16x8_t*>(xp + i0 + si);
-        const u16x8_t v2 = *reinterpret_cast<const u16x8_t*>(xp + i0 + 2 * si);
-        const u16x8_t v3 = *reinterpret_cast<const u16x8_t*>(xp + i0 + 3 * si);
-        apply(v0, e0); apply(v1, e0 + st); apply(v2, e0 + 2 * st); apply(v3, e0 + 3 * st);
+    if constexpr (U == 4) {      // the shipped form, written out (the generic loop below costs it a 20-byte spill)
+        for (; row + 3 * a.R < row1; row += 4 * a.R) {
+            const size_t e0 = img + (size_t)row * a.C + cc * 8, st = (size_t)a.R * a.C;
+            const size_t i0 = (size_t)row * pitch, si = (size_t)a.R * pitch;
+            const u16x8_t v0 = *reinterpret_cast<const u16x8_t*>(xp + i0);
+            const u16x8_t v1 = *reinterpret_cast<const u16x8_t*>(xp + i0 + si);
+            const u16x8_t v2 = *reinterpret_cast<const u16x8_t*>(xp + i0 + 2 * si);
+            const u16x8_t v3 = *reinterpret_cast<const u16x8_t*>(xp + i0 + 3 * si);
+            apply(v0, e0); apply(v1, e0 + st); apply(v2, e0 + 2 * st); apply(v3, e0 + 3 * st);
+        }
+    } else {
+        for (; row + (U - 1) * a.R < row1; row += U * a.R) {
+            const size_t e0 = img + (size_t)row * a.C + cc * 8, st = (size_t)a.R * a.C;
+            const size_t i0 = (size_t)row * pitch, si = (size_t)a.R * pitch;
+            u16x8_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const u16x8_t*>(xp + i0 + u * si);
+#pragma unroll
+            for (int u = 0; u < U; ++u) apply(v[u], e0 + u * st);
+        }
     }
     for (; row < row1; row += a.R) {
         const size_t e = img + (size_t)row * a.C + cc * 8;
@@ -1113,6 +1126,7 @@ static size_t nh_onepass_counter_bytes_fwd(int N) { return (((size_t)N * sizeof(
 #ifdef PGN_TUNING_HOOKS
 unsigned long long* g_nh_dbg = nullptr;
 int g_nh_reverse = 1;
+int g_apply_variant = 0; // rows in flight / register budget of pgn_gn_nhwc_apply_kernel (scripts/gn_apply_sweep.py)
 int g_brs_variant = 0;   // rows in flight / register budget of pgn_bias_res_stats_kernel (scripts/producer_stats_exp.py)
 int g_nh_target_wgs = 768, g_nh_min_rows_per_lane = 24;
 #else
@@ -1247,6 +1261,7 @@ static bool nh_ranges_overlap(const void* p, size_t pb, const void* q, size_t qb
 extern "C" void pgn_groupnorm_nhwc_debug_buffer(void* p) { g_nh_dbg = (unsigned long long*)p; }
 extern "C" void pgn_groupnorm_nhwc_reverse(int on) { g_nh_reverse = on; }
 extern "C" void pgn_bias_res_stats_variant(int v) { g_brs_variant = v; }
+extern "C" void pgn_gn_apply_variant(int v) { g_apply_variant = v; }
 extern "C" void pgn_groupnorm_nhwc_tuning(int target_wgs, int min_rows_per_lane) {
     g_nh_target_wgs = target_wgs;
     g_nh_min_rows_per_lane = min_rows_per_lane;
@@ -1256,6 +1271,21 @@ extern "C" void pgn_groupnorm_nhwc_tuning(int target_wgs, int min_rows_per_lane)
 extern "C" size_t pgn_groupnorm_nhwc_workspace_bytes(int N, int C, int HW, int G) {
     return nh_workspace_need(N, C, HW, G);
 }
+
+// the apply launch (grid, block, s in scope); the measurement build can pick rows in flight / register budget
+#ifdef PGN_TUNING_HOOKS
+#define PGN_NH_APPLY(DT, ADD, ACT, ARGS)                                                                             \
+    do {                                                                                                             \
+        if (g_apply_variant == 1) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, ADD, ACT, 8, 4>), grid, block, 0, s, ARGS);      \
+        else if (g_apply_variant == 2) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, ADD, ACT, 2, 8>), grid, block, 0, s, ARGS); \
+        else if (g_apply_variant == 3) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, ADD, ACT, 2, 4>), grid, block, 0, s, ARGS); \
+        else if (g_apply_variant == 4) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, ADD, ACT, 4, 8>), grid, block, 0, s, ARGS); \
+        else hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, ADD, ACT, 4, 4>), grid, block, 0, s, ARGS);            \
+    } while (0)
+#else
+#define PGN_NH_APPLY(DT, ADD, ACT, ARGS)                                                                             \
+    hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, ADD, ACT, 4, 4>), grid, block, 0, s, ARGS)
+#endif
 
 // pre1 / pre2: partial statistics the producers of x / x2 already wrote (pgn_bias_residual_add_stats), or nullptr: the
 // statistics launch runs here
@@ -1324,8 +1354,8 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
 #define PGN_NH_PRE(DT)                                                                                               \
     do {                                                                                                             \
         hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<DT>), dim3(N * G), dim3(NH_FIN_THREADS), 0, s, f);           \
-        if (act) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, false, true>), grid, block, 0, s, f);              \
-        else hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, false, false>), grid, block, 0, s, f);                 \
+        if (act) PGN_NH_APPLY(DT, false, true, f);                                                                   \
+        else PGN_NH_APPLY(DT, false, false, f);                                                                      \
     } while (0)
         if (dtype == PGN_BF16) PGN_NH_PRE(PGN_BF16);
         else PGN_NH_PRE(PGN_F16);
@@ -1433,10 +1463,10 @@ static int nh_run(const void* x, int C1, const void* x2, void* y, int dtype, con
         if (has_add) hipLaunchKernelGGL((pgn_gn_nhwc_stats_kernel<DT, true>), grid, block, lds, s, a);               \
         else hipLaunchKernelGGL((pgn_gn_nhwc_stats_kernel<DT, false>), grid, block, lds, s, a);                      \
         hipLaunchKernelGGL((pgn_gn_nhwc_finalize_kernel<DT>), dim3(N * G), dim3(NH_FIN_THREADS), 0, s, a);           \
-        if (has_add && act) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, true, true>), grid, block, 0, s, a);    \
-        else if (has_add) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, true, false>), grid, block, 0, s, a);     \
-        else if (act) hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, false, true>), grid, block, 0, s, a);         \
-        else hipLaunchKernelGGL((pgn_gn_nhwc_apply_kernel<DT, false, false>), grid, block, 0, s, a);                 \
+        if (has_add && act) PGN_NH_APPLY(DT, true, true, a);                                                         \
+        else if (has_add) PGN_NH_APPLY(DT, true, false, a);                                                          \
+        else if (act) PGN_NH_APPLY(DT, false, true, a);                                                              \
+        else PGN_NH_APPLY(DT, false, false, a);                                                                      \
     } while (0)
     if (dtype == PGN_BF16) PGN_NH_LAUNCH(PGN_BF16);
     else PGN_NH_LAUNCH(PGN_F16);
